@@ -1,0 +1,168 @@
+"""Pins the CPU oracle (oracle/quadsim_oracle.c, f64 build) against the golden
+vectors captured from the real reference by oracle/gen_goldens.py.
+
+Tolerance: 1e-12 absolute/relative (both sides are IEEE double; differences are
+summation order only).  The f32 build of the same source is held to the
+north_star's 1e-5 to show the formulas survive binary32."""
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from oracle.pyoracle import PAR_NOMINAL, REC_LEN, Oracle
+
+TOL = dict(rtol=1e-12, atol=1e-12)
+
+
+def test_g2_transforms(oracle64):
+    g = load_golden("g2_transforms")
+    for i in range(len(g["quat"])):
+        np.testing.assert_allclose(oracle64.quat2euler(g["quat"][i]), g["quat2euler"][i], **TOL)
+        np.testing.assert_allclose(oracle64.quat2rot(g["quat"][i]), g["quat2rot"][i], **TOL)
+        np.testing.assert_allclose(oracle64.euler2quat(g["euler"][i]), g["euler2quat"][i], **TOL)
+        np.testing.assert_allclose(oracle64.rot2euler(g["rot"][i]), g["rot2euler"][i], **TOL)
+    # the saturation branches are present in the fixture
+    assert np.sum(np.abs(g["rot"][:, 1, 2]) >= 1) > 50
+    assert np.sum(np.abs(g["quat2euler"][:, 0]) == np.pi / 2) > 10
+
+
+def test_g1_drone_step(oracle64):
+    g = load_golden("g1_drone_step")
+    n = len(g["state"])
+    fired = 0
+    for i in range(n):
+        s2, up2, over = oracle64.drone_step(g["state"][i], g["u_prev"][i], g["u"][i], dt=float(g["dt"]))
+        np.testing.assert_allclose(s2, g["state_out"][i], **TOL)
+        np.testing.assert_allclose(up2, g["u_prev_out"][i], **TOL)
+        assert over == int(g["limited"][i])
+        fired += over
+    assert fired > 500 and fired < n - 500
+
+
+def test_g3_controller(oracle64):
+    g = load_golden("g3_controller")
+    for i in range(len(g["state_des"])):
+        u, sd = oracle64.ctrl_pid(g["state_des"][i], g["state_now"][i], float(g["mass"]))
+        np.testing.assert_allclose(u, g["u_pid"][i], **TOL)
+        np.testing.assert_allclose(sd, g["state_des_after_pid"][i], **TOL)
+        u, sd = oracle64.ctrl_vel(g["state_des"][i], g["state_now"][i], g["state_last"][i], float(g["mass"]))
+        np.testing.assert_allclose(u, g["u_vel"][i], **TOL)
+        np.testing.assert_allclose(sd, g["state_des_after_vel"][i], **TOL)
+
+
+def _check_single_steps(orc, g, kind, par=PAR_NOMINAL, prefix="", tol=TOL, rew_atol=1e-12):
+    rb, ra = g[prefix + "rec_before"], g[prefix + "rec_after"]
+    for t in range(len(rb)):
+        rec, obs, rew, done, flags = orc.env_step(rb[t], g[prefix + "actions"][t], par=par, kind=kind)
+        np.testing.assert_allclose(rec, ra[t], **tol)
+        np.testing.assert_allclose(obs, g[prefix + "obs"][t], **tol)
+        assert abs(rew - g[prefix + "reward"][t]) <= rew_atol * max(1.0, abs(ra[t][38]))
+        assert done == bool(g[prefix + "done"][t])
+        assert (flags & 7) == int(g[prefix + "flags"][t])
+
+
+@pytest.mark.parametrize("name,kind", [("g4_traj_v0", 0), ("g4_traj_v2", 1)])
+def test_g4_single_steps(oracle64, name, kind):
+    _check_single_steps(oracle64, load_golden(name), kind)
+
+
+@pytest.mark.parametrize("name,kind", [("g4_traj_v0", 0), ("g4_traj_v2", 1)])
+def test_g4_closed_loop_with_autoreset(oracle64, name, kind):
+    """free-running oracle vec env (N=1, auto-reset) reproduces the whole
+    1500-step reference trajectory, resets included; q_des persists over resets."""
+    g = load_golden(name)
+    rec = oracle64.env_init(1)
+    par = np.array([PAR_NOMINAL], np.float64)
+    first = oracle64.vec_reset(rec, par)
+    np.testing.assert_allclose(first[0], g["first_obs"], **TOL)
+    for t in range(len(g["actions"])):
+        np.testing.assert_allclose(rec[0], g["rec_before"][t], rtol=1e-9, atol=1e-9)
+        obs, rew, done, flags, term = oracle64.vec_step(rec, par, g["actions"][t][None], kind=kind, want_term=True)
+        assert bool(done[0]) == bool(g["done"][t])
+        if done[0]:
+            np.testing.assert_allclose(term[0], g["obs"][t], rtol=1e-9, atol=1e-9)
+            np.testing.assert_allclose(obs[0], g["reset_obs"][t], rtol=1e-9, atol=1e-9)
+        else:
+            np.testing.assert_allclose(obs[0], g["obs"][t], rtol=1e-9, atol=1e-9)
+        assert abs(rew[0] - g["reward"][t]) < 1e-9
+    assert g["done"].sum() >= 10
+
+
+def test_g4_known_answers():
+    """spot values quoted in SURVEY.md section 8c"""
+    g = load_golden("g4_traj_v0")
+    np.testing.assert_allclose(g["first_obs"], [1.8] + [0.0] * 11, atol=1e-15)
+    a0 = g["actions"][0].astype(np.float64)
+    assert abs(g["reward"][0] - (-6.0 - 0.1 * np.linalg.norm(a0))) < 1e-12
+    assert abs(g["rec_after"][0][5] - (-0.1962)) < 1e-12 and abs(g["rec_after"][0][13 + 5] - (-0.1962)) < 1e-12
+    g2 = load_golden("g4_traj_v2")
+    assert abs(g2["reward"][0] - (-1.8 - 0.1 * np.linalg.norm(g2["actions"][0].astype(np.float64)))) < 1e-12
+
+
+def test_g5_policy_episode(oracle64):
+    g = load_golden("g5_policy_episode")
+    _check_single_steps(oracle64, g, 0)
+    assert (g["flags"] & 1).sum() == 183 and g["flags"][-1] & 4 and g["done"][-1] and len(g["done"]) == 600
+
+
+def test_g6_sim_pid(oracle64):
+    g = load_golden("g6_sim_pid")
+    S, U, s_fin, sdes_fin = oracle64.sim_pid(len(g["states"]), g["ini_state"], g["state_des"])
+    np.testing.assert_allclose(S, g["states"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(U, g["u"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(s_fin, g["final_state"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(sdes_fin, g["final_state_des"], rtol=1e-9, atol=1e-10)
+    np.testing.assert_allclose(s_fin[:3], [-0.2, 0.2, 0.2], atol=1e-3)
+
+
+def test_g7_domain_rand(oracle64):
+    g = load_golden("g7_domain_rand")
+    for kind in (0, 1):
+        for j in range(3):
+            key = "k%d_s%d_" % (kind, j)
+            _check_single_steps(oracle64, g, kind, par=tuple(g[key + "par"]), prefix=key)
+
+
+@pytest.mark.parametrize("name,kind", [("g4_traj_v0", 0), ("g4_traj_v2", 1), ("g5_policy_episode", 0)])
+def test_f32_build_within_north_star_tolerance(oracle32, name, kind):
+    """binary32 evaluation of the same formulas from identical (f32-rounded)
+    inputs stays within 1e-5 per step; done/flags never flip on these data."""
+    g = load_golden(name)
+    rb = g["rec_before"].astype(np.float32)
+    worst = 0.0
+    o64 = Oracle("f64")
+    for t in range(0, len(rb), 3):
+        a = g["actions"][t]
+        rec64, obs64, rew64, done64, fl64 = o64.env_step(rb[t].astype(np.float64), a, kind=kind)
+        rec32, obs32, rew32, done32, fl32 = oracle32.env_step(rb[t], a, kind=kind)
+        np.testing.assert_allclose(rec32[:38], rec64[:38], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(obs32, obs64, rtol=1e-5, atol=2e-5)
+        assert abs(rew32 - rew64) <= 1e-5 * max(1.0, abs(rec64[38]))
+        assert done32 == done64 and (fl32 & 7) == (fl64 & 7)
+        worst = max(worst, float(np.max(np.abs(obs32 - obs64))))
+    assert worst < 2e-5
+
+
+def test_philox_known_answer(oracle64):
+    """Random123 known-answer test for Philox4x32-10 (counter/key all zero and
+    the 'pi' vector), which rocRAND's engine implements."""
+    z = oracle64.philox(0, 0, 0)
+    assert [hex(int(x)) for x in z] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    ones = oracle64.philox(0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFF, 0xFFFFFFFFFFFFFFFF)
+    assert [hex(int(x)) for x in ones] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+    # counter = (0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), key = (0xa4093822, 0x299f31d0)
+    pi = oracle64.philox(0x299f31d0a4093822, 0x0370734413198a2e, 0x85a308d3243f6a88)
+    assert [hex(int(x)) for x in pi] == ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+
+
+def test_random_init_ranges(oracle64):
+    rr = (0.5, 0.1, 0.2, 0.1, 0.8, 1.2, 0.8, 1.2)
+    U = []
+    for gid in range(400):
+        sc, st, par, u = oracle64.random_init(1234, 0, gid, 7, rr)
+        U.append(u)
+        assert np.all(np.abs(sc[0:3] - [8, -50, 5]) <= 0.5 + 1e-6) and np.all(np.abs(sc[3:6]) <= 0.1)
+        assert abs(np.linalg.norm(sc[6:10]) - 1) < 1e-6 and np.all(np.abs(sc[10:13]) <= 0.1)
+        np.testing.assert_array_equal(st, [10, -50, 5, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0])
+        assert 0.8 * 0.18 <= par[0] <= 1.2 * 0.18 * (1 + 1e-6)
+    U = np.array(U)
+    assert U.min() > 0 and U.max() <= 1 and abs(U.mean() - 0.5) < 0.02 and abs(U.var() - 1 / 12) < 0.01
