@@ -1,0 +1,184 @@
+/*
+ * quadsim.h -- C ABI of libquadsim_hip.so: the MI355X (gfx950) drop-in for
+ * QuadSim's env.step() hot path (docking-v0 / docking-v2).
+ *
+ * The reference has no FFI of its own -- the path is plain Python classes
+ * (SURVEY.md section 8b).  Each entry point below therefore cites the Python
+ * method it replaces; INTEGRATION.md shows the ctypes binding a maintainer adds
+ * to gym_docking to switch over.  Plain pointers and sizes only; no torch, no
+ * HIP types in the signatures (a hipStream_t travels as void*).
+ *
+ * Conventions
+ *   - every function returns 0 (QS_OK) or a negative QS_ERR_*; the message is
+ *     available from qs_last_error() (thread-local).
+ *   - all data buffers are caller-owned.  With io_space == QS_IO_DEVICE they
+ *     are device pointers on cfg.device (e.g. torch.Tensor.data_ptr()); with
+ *     QS_IO_HOST they are host pointers and the call stages them through the
+ *     GPU and returns after the result is back (single-env gym shim).
+ *   - device calls are asynchronous on the handle's stream; qs_sync() waits.
+ *   - a handle is not thread-safe; distinct handles are independent (one per
+ *     GPU / per process).
+ *   - there is no CPU fallback: creation fails if no HIP device is present.
+ *
+ * Layouts (row-major, float32 unless noted)
+ *   state vector [13] = pos(3) vel(3) quat w,x,y,z(4) body-rates(3)   (dynamics/quadrotor.py:25)
+ *   actions [N,4] in [-1,1]                                             (docking_env.py:93)
+ *   obs [N,12] = rel_pos rel_vel rel_euler rel_euler_rates              (docking_env.py:287-293)
+ *   done [N] uint8; flags [N] uint8 (QS_FLAG_*)
+ */
+#ifndef QUADSIM_H
+#define QUADSIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QS_VERSION 100 /* 0.1.0 */
+
+enum {
+    QS_OK = 0,
+    QS_ERR_INVALID = -1, /* bad argument / shape */
+    QS_ERR_HIP = -2,     /* a HIP runtime call failed */
+    QS_ERR_NO_DEVICE = -3,
+    QS_ERR_NOMEM = -4
+};
+
+/* env kinds: gym ids registered at gym-docking/gym_docking/__init__.py:3-17 */
+enum {
+    QS_KIND_DOCKING_V0 = 0, /* DockingEnv,       envs/docking_env.py        */
+    QS_KIND_DOCKING_V2 = 1  /* MovingDockingEnv, envs/moving_docking_env.py */
+};
+
+enum {
+    QS_INTEG_FROZEN = 0, /* what Drone.step computes: RK45 over a frozen RHS == s + dt*df(s,u_prev)
+                            (dynamics/quadrotor.py:115-134).  The parity mode. */
+    QS_INTEG_RK4 = 1     /* classic RK4 re-evaluating df at the stage states (the intended physics;
+                            no counterpart in the reference) */
+};
+
+enum { QS_IO_DEVICE = 0, QS_IO_HOST = 1 };
+
+/* bits of flags[] -- info['flag_docking'], info['done_overlimit'] (docking_env.py:226-229) */
+enum {
+    QS_FLAG_DOCKED = 1,
+    QS_FLAG_OVERLIMIT = 2,
+    QS_FLAG_OVERTIME = 4,       /* t >= 600, docking_env.py:152 */
+    QS_FLAG_CHASER_LIMITED = 8, /* Drone.attitude_limit fired (quadrotor.py:135-138) */
+    QS_FLAG_TARGET_LIMITED = 16
+};
+
+enum {
+    QS_RANDOMISE_NONE = 0,  /* nominal reset states (docking_env.py:34-57) -- the reference's behaviour */
+    QS_RANDOMISE_INIT = 1,  /* + rocRAND jitter of the chaser's initial state (the commented ranges at docking_env.py:34-37) */
+    QS_RANDOMISE_PARAMS = 2 /* + per-episode mass / inertia scale (BASELINE config 5) */
+};
+
+typedef struct QsEnv QsEnv;
+
+typedef struct QsConfig {
+    int32_t struct_size; /* sizeof(QsConfig), set by qs_config_default */
+    int32_t kind;        /* QS_KIND_* */
+    int64_t num_envs;    /* N parallel envs on this device */
+    int32_t device;      /* HIP device ordinal */
+    int32_t integrator;  /* QS_INTEG_* */
+    float dt;            /* 0.02 (dynamics/quadrotor.py:10) */
+    int32_t auto_reset;  /* 1: SB2 VecEnv semantics (reset on done inside step, terminal obs kept) ;
+                            0: gym.Env semantics (step never resets, docking_env.py:104-231) */
+    int32_t randomise;   /* QS_RANDOMISE_* */
+    int32_t io_space;    /* QS_IO_* */
+    uint64_t seed;          /* Philox key */
+    uint64_t env_id_offset; /* global id of env 0 of this handle (shard offset; RNG is keyed by global id) */
+    float init_range[4];    /* half-ranges: chaser pos [m], vel [m/s], euler [rad], body rates [rad/s] */
+    float mass_scale[2];    /* [lo,hi] multiplier of mass    (QS_RANDOMISE_PARAMS) */
+    float inertia_scale[2]; /* [lo,hi] multiplier of Ixx,Iyy,Izz */
+    float mass;             /* nominal 0.18 (quadrotor.py:16) */
+    float inertia[3];       /* nominal diag (2.5e-4, 2.32e-4, 3.738e-4) (quadrotor.py:17-19) */
+    void *stream;           /* hipStream_t to launch on when external_stream != 0 (NULL = the device's default stream) */
+    int32_t external_stream; /* 0: the handle creates and owns a stream ; 1: launch on `stream` (e.g. torch's current stream) */
+    int32_t reserved;
+} QsConfig;
+
+/* fills *cfg with the reference's constants: v0, N=1, frozen, dt 0.02, auto_reset 0, no randomisation */
+int qs_config_default(QsConfig *cfg);
+
+int qs_version(void);
+const char *qs_last_error(void);
+
+/* DockingEnv.__init__ / MovingDockingEnv.__init__ (docking_env.py:15-102) for N envs.
+ * All envs start in the nominal state with target_state_des attitude (1,0,0,0). */
+int qs_create(const QsConfig *cfg, QsEnv **out);
+int qs_destroy(QsEnv *env);
+
+/* DockingEnv.reset (docking_env.py:233-244) for the envs with mask[i] != 0 (mask NULL = all).
+ * obs_out [N,12] nullable; rows of unmasked envs are left untouched.
+ * Does not touch the target's desired attitude (the reference never resets it). */
+int qs_reset(QsEnv *env, const uint8_t *mask, float *obs_out);
+
+/* DockingEnv.step (docking_env.py:104-231) / MovingDockingEnv.step (moving_docking_env.py:111-192)
+ * for all N envs in one fused kernel.  actions [N,4]; obs [N,12]; reward [N]; done [N];
+ * flags [N] nullable; terminal_obs [N,12] nullable (rows written only where done && auto_reset:
+ * SB2's infos[i]['terminal_observation']). */
+int qs_step(QsEnv *env, const float *actions, float *obs, float *reward, uint8_t *done, uint8_t *flags,
+            float *terminal_obs);
+
+/* T consecutive steps in ONE launch, env state held in registers (the loop body of the
+ * trainer's Runner, rl_baselines/ppo2/ppo2.py:472-499, with the policy's actions pre-staged).
+ * Requires auto_reset.  actions [T,N,4], or NULL: U(-1,1) actions drawn in-kernel from the
+ * action stream (synthetic roll-outs).  obs [T,N,12], reward [T,N], done [T,N], flags [T,N] nullable.
+ * Results are identical to T calls of qs_step. */
+int qs_rollout(QsEnv *env, int64_t T, const float *actions, float *obs, float *reward, uint8_t *done,
+               uint8_t *flags);
+
+/* U(-1,1) synthetic actions [T,N,4] for steps step0 .. step0+T-1 (rocRAND Philox4x32-10 action stream;
+ * identical to what qs_rollout draws in-kernel when actions == NULL). */
+int qs_fill_random_actions(QsEnv *env, int64_t T, uint64_t step0, float *actions);
+
+/* Internal state in the reference's own terms (any pointer may be NULL = skip):
+ * chaser [N,13] env.state_chaser; target [N,13] env.state_target; u_prev [N,8] = chaser.u, target.u
+ * (last LIMITED controls, quadrotor.py:140); qdes [N,4] env.target_state_des[6:10];
+ * last_shaping [N]; t [N] (env.t as float). */
+int qs_get_state(QsEnv *env, float *chaser, float *target, float *u_prev, float *qdes, float *last_shaping,
+                 float *t);
+int qs_set_state(QsEnv *env, const float *chaser, const float *target, const float *u_prev, const float *qdes,
+                 const float *last_shaping, const float *t);
+
+/* per-env mass [N] and diagonal inertia [N,3] (Drone.mass / Drone.Inertia; also sets F_max = 4 m g,
+ * controller.mass and action_mean/std = m g / 2 consistently).  Switches the handle to per-env params. */
+int qs_set_params(QsEnv *env, const float *mass, const float *inertia);
+int qs_get_params(QsEnv *env, float *mass, float *inertia);
+
+/* global step counter k (number of qs_step calls / rollout steps so far); keys the RNG streams */
+int qs_get_step_counter(QsEnv *env, uint64_t *k);
+int qs_set_step_counter(QsEnv *env, uint64_t k);
+
+/* external != 0: launch on hip_stream from now on (NULL = default stream); external == 0: back to an owned stream */
+int qs_set_stream(QsEnv *env, void *hip_stream, int32_t external);
+int qs_sync(QsEnv *env);
+
+/* HIP-event stopwatch on the handle's stream (bench.py: kernel time on the launching stream) */
+int qs_timer_start(QsEnv *env);
+int qs_timer_stop(QsEnv *env, float *elapsed_ms); /* synchronises on the stop event */
+
+/* ---- layer-1 entry points: n independent drones / controllers (n need not equal N) ----------- */
+
+/* Drone.step (dynamics/quadrotor.py:126-144): state [n,13] in/out, u_prev [n,4] in/out (Drone.u),
+ * u [n,4] commanded control, par [n,4] = mass,Ixx,Iyy,Izz or NULL (nominal), limited [n] u8 nullable. */
+int qs_drone_step(QsEnv *env, int64_t n, float *state, float *u_prev, const float *u, const float *par,
+                  uint8_t *limited);
+
+/* controller.PID (mode 0, controller/PIDController.py:179-185) or controller.vel_controller
+ * (mode 1, :106-141): state_des [n,13] in/out (the reference mutates [6:12]), state [n,13],
+ * state_last [n,13] (mode 1 only, else NULL), mass scalar, u_out [n,4]. */
+int qs_ctrl(QsEnv *env, int64_t n, int32_t mode, float *state_des, const float *state, const float *state_last,
+            float mass, float *u_out);
+
+/* state2rel over dock-port states (docking_env.py:257-295 with quadrotor.py:213-224):
+ * chaser [n,13], target [n,13] -> obs [n,12] */
+int qs_rel_obs(QsEnv *env, int64_t n, const float *chaser, const float *target, float *obs);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* QUADSIM_H */

@@ -1,0 +1,17 @@
+"""quadsim_amd -- MI355X-native drop-in for QuadSim's env.step() hot path.
+
+Python host code over a C ABI (include/quadsim.h) into hand-written HIP kernels
+for gfx950.  No CPU fallback: importing is cheap, but every env needs the built
+library and a GPU.
+"""
+from . import _lib
+from ._lib import QuadsimError, build_library
+from .drone import Drone, controller, ctrl_batch, drone_step_batch, rel_obs_batch
+from .envs import DockingEnv, MovingDockingEnv, make, register_gym_ids
+from .vec_env import C3_INIT_RANGE, VecDockingEnv, shard_range
+
+__all__ = ["VecDockingEnv", "DockingEnv", "MovingDockingEnv", "Drone", "controller", "make", "register_gym_ids",
+           "shard_range", "build_library", "QuadsimError", "C3_INIT_RANGE", "drone_step_batch", "ctrl_batch",
+           "rel_obs_batch", "_lib"]
+
+register_gym_ids()

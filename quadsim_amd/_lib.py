@@ -1,0 +1,124 @@
+"""ctypes binding of libquadsim_hip.so (the C ABI declared in include/quadsim.h).
+
+There is deliberately no fallback of any kind: if the HIP library is missing or
+no MI355X is visible, loading / qs_create raise.  Nothing here imports oracle/.
+"""
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libquadsim_hip.so")
+SOURCES = [os.path.join(CSRC, "quadsim_hip.hip")]
+HEADERS = [os.path.join(CSRC, "quadsim_device.hpp"), os.path.join(HERE, "..", "include", "quadsim.h")]
+
+QS_OK = 0
+KIND_V0, KIND_V2 = 0, 1
+INTEG_FROZEN, INTEG_RK4 = 0, 1
+IO_DEVICE, IO_HOST = 0, 1
+RANDOMISE_NONE, RANDOMISE_INIT, RANDOMISE_PARAMS = 0, 1, 2
+FLAG_DOCKED, FLAG_OVERLIMIT, FLAG_OVERTIME, FLAG_CHASER_LIMITED, FLAG_TARGET_LIMITED = 1, 2, 4, 8, 16
+
+EXPORTS = [
+    "qs_config_default", "qs_version", "qs_last_error", "qs_create", "qs_destroy", "qs_reset", "qs_step",
+    "qs_rollout", "qs_fill_random_actions", "qs_get_state", "qs_set_state", "qs_set_params", "qs_get_params",
+    "qs_get_step_counter", "qs_set_step_counter", "qs_set_stream", "qs_sync", "qs_timer_start", "qs_timer_stop",
+    "qs_drone_step", "qs_ctrl", "qs_rel_obs",
+]
+
+
+class QsConfig(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_int32), ("kind", C.c_int32), ("num_envs", C.c_int64), ("device", C.c_int32),
+        ("integrator", C.c_int32), ("dt", C.c_float), ("auto_reset", C.c_int32), ("randomise", C.c_int32),
+        ("io_space", C.c_int32), ("seed", C.c_uint64), ("env_id_offset", C.c_uint64),
+        ("init_range", C.c_float * 4), ("mass_scale", C.c_float * 2), ("inertia_scale", C.c_float * 2),
+        ("mass", C.c_float), ("inertia", C.c_float * 3), ("stream", C.c_void_p),
+        ("external_stream", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class QuadsimError(RuntimeError):
+    pass
+
+
+def hipcc_path():
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise QuadsimError("hipcc not found: cannot build libquadsim_hip.so")
+
+
+def build_library(force=False, verbose=False):
+    """hipcc --offload-arch=gfx950 -shared: cross-compiles without a GPU."""
+    deps = SOURCES + HEADERS
+    if (not force and os.path.exists(LIB_PATH)
+            and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps)):
+        return LIB_PATH
+    cmd = [hipcc_path(), "-std=c++20", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared",
+           "-Wno-unused-result", *SOURCES, "-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """dlopen the library; raises QuadsimError if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise QuadsimError(
+            "%s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). quadsim_amd has no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    vp, i64, u64, i32, f32 = C.c_void_p, C.c_int64, C.c_uint64, C.c_int32, C.c_float
+    sig = {
+        "qs_config_default": [C.POINTER(QsConfig)],
+        "qs_version": [],
+        "qs_create": [C.POINTER(QsConfig), C.POINTER(vp)],
+        "qs_destroy": [vp],
+        "qs_reset": [vp, vp, vp],
+        "qs_step": [vp, vp, vp, vp, vp, vp, vp],
+        "qs_rollout": [vp, i64, vp, vp, vp, vp, vp],
+        "qs_fill_random_actions": [vp, i64, u64, vp],
+        "qs_get_state": [vp] + [vp] * 6,
+        "qs_set_state": [vp] + [vp] * 6,
+        "qs_set_params": [vp, vp, vp],
+        "qs_get_params": [vp, vp, vp],
+        "qs_get_step_counter": [vp, C.POINTER(u64)],
+        "qs_set_step_counter": [vp, u64],
+        "qs_set_stream": [vp, vp, i32],
+        "qs_sync": [vp],
+        "qs_timer_start": [vp],
+        "qs_timer_stop": [vp, C.POINTER(f32)],
+        "qs_drone_step": [vp, i64, vp, vp, vp, vp, vp],
+        "qs_ctrl": [vp, i64, i32, vp, vp, vp, f32, vp],
+        "qs_rel_obs": [vp, i64, vp, vp, vp],
+    }
+    for name, args in sig.items():
+        fn = getattr(lib, name)
+        fn.argtypes = args
+        fn.restype = C.c_int
+    lib.qs_last_error.argtypes = []
+    lib.qs_last_error.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc, what=""):
+    if rc != QS_OK:
+        msg = load().qs_last_error().decode("utf-8", "replace")
+        raise QuadsimError("%s failed (%d): %s" % (what or "quadsim call", rc, msg))
+
+
+def default_config():
+    cfg = QsConfig()
+    check(load().qs_config_default(C.byref(cfg)), "qs_config_default")
+    return cfg

@@ -1,0 +1,445 @@
+// quadsim_device.hpp -- per-env device math of the fused docking step (gfx950).
+//
+// One lane integrates one env: chaser + target drone, target PID, dock ports,
+// relative observation, reward, done.  All state lives in VGPRs between the
+// tile load and the tile store.  Formulas follow SURVEY.md Appendix A, which is
+// the validated closed form of
+//   dynamics/quadrotor.py, utils/transform.py, controller/PIDController.py,
+//   gym-docking/gym_docking/envs/{docking_env,moving_docking_env}.py
+// (file:line cited per function).  fp32 throughout; where binary32 would lose
+// digits to cancellation the evaluation order is chosen for accuracy, never to
+// mimic the reference's float64 rounding (parity is to 1e-5, not bitwise).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <rocrand/rocrand_philox4x32_10.h>
+#include <stdint.h>
+
+namespace qs {
+
+constexpr float kG = 9.81f;                       // dynamics/quadrotor.py:15
+constexpr float kL = 0.086f;                      // :20
+constexpr float kLambda = (float)(1.5e-9 / 6.11e-8);  // km/kf, :43-45
+constexpr float kPi = 3.14159265358979323846f;
+constexpr float kHalfPi = 1.57079632679489661923f;
+constexpr float kLim85 = 1.4835298641951802f;     // deg2rad(85),  quadrotor.py:156
+constexpr float kLim175 = 3.0543261909900763f;    // deg2rad(175), quadrotor.py:162
+constexpr float kLim10 = 0.17453292519943295f;    // deg2rad(10),  docking_env.py:132
+constexpr float kTMax = 600.0f;                   // docking_env.py:152
+
+// AoSoA tile: 64 envs (one wavefront) x kRecWords fields, field-major inside the tile
+constexpr int kTile = 64;
+constexpr int kRecWords = 40;
+constexpr int kParWords = 4;
+// field offsets inside an env record (same order as the oracle's "rec")
+constexpr int F_SC = 0, F_ST = 13, F_UC = 26, F_UT = 30, F_QD = 34, F_LS = 38, F_T = 39;
+
+enum : unsigned { FLAG_DOCKED = 1, FLAG_OVERLIMIT = 2, FLAG_OVERTIME = 4, FLAG_CLIM = 8, FLAG_TLIM = 16 };
+enum : uint64_t { STREAM_AUTORESET = 0, STREAM_RESET = 1, STREAM_ACTIONS = 2 };
+
+struct Par {
+    float m, Ixx, Iyy, Izz;
+};
+
+// env-kind constants, uniform over the launch (SGPRs)
+struct EnvConst {
+    int kind;      // 0 docking-v0, 1 docking-v2
+    float dt;
+    float rmax;    // 3 (docking_env.py:141) / 10 (moving_docking_env.py:148)
+    float vdes_x;  // 0 / 0.2 (moving_docking_env.py:62)
+};
+
+// ---------------------------------------------------------------------------
+// scalar math.  1-ulp hardware reciprocal / rsqrt / sqrt; ocml for the inverse
+// trig (accurate to ~1 ulp, arguments are bounded so no slow paths are taken).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ float q_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float q_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
+__device__ __forceinline__ float q_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+__device__ __forceinline__ float q_asin(float x) { return asinf(x); }
+__device__ __forceinline__ float q_atan2(float y, float x) { return atan2f(y, x); }
+__device__ __forceinline__ void q_sincos(float x, float &s, float &c) { sincosf(x, &s, &c); }
+
+// off-diagonal entries of the reference's quat2rot (diagonal is identically 1):
+// utils/transform.py:4-20 == dynamics/quadrotor.py:226-245.  Element-wise
+// qa_hat*qa_hat with the NORMALISED vector part, linear term with the
+// UN-normalised scalar part.
+struct Rot {
+    float r01, r02, r10, r12, r20, r21;
+};
+__device__ __forceinline__ Rot quat2rot(const float q[4])
+{
+    float inv = q_rsqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    float n1 = q[1] * inv, n2 = q[2] * inv, n3 = q[3] * inv;
+    float w2 = 2.0f * q[0];
+    float s1 = 2.0f * n1 * n1, s2 = 2.0f * n2 * n2, s3 = 2.0f * n3 * n3;
+    Rot R;
+    R.r01 = s3 - w2 * n3;
+    R.r10 = s3 + w2 * n3;
+    R.r02 = s2 + w2 * n2;
+    R.r20 = s2 - w2 * n2;
+    R.r12 = s1 - w2 * n1;
+    R.r21 = s1 + w2 * n1;
+    return R;
+}
+
+// utils/transform.py:94-120.  The three branches collapse to: phi = asin(clamp r12),
+// theta = 0 when r12 >= 1 or r12 < -1.
+__device__ __forceinline__ void quat2euler(const float q[4], float &phi, float &theta, float &psi)
+{
+    float w = q[0], x = q[1], y = q[2], z = q[3];
+    float r10 = 2.0f * (x * y - w * z);
+    float r11 = w * w - x * x + y * y - z * z;
+    float r12 = 2.0f * (w * x + y * z);
+    float r02 = 2.0f * (x * z - w * y);
+    float r22 = w * w - x * x - y * y + z * z;
+    psi = q_atan2(-r10, r11);
+    phi = q_asin(fminf(fmaxf(r12, -1.0f), 1.0f));
+    float th = q_atan2(-r02, r22);
+    theta = (r12 >= 1.0f || r12 < -1.0f) ? 0.0f : th;
+}
+
+// yaw only (what hover/vel_controller read back from state_des, PIDController.py:87-88)
+__device__ __forceinline__ float quat2yaw(const float q[4])
+{
+    float w = q[0], x = q[1], y = q[2], z = q[3];
+    float r10 = 2.0f * (x * y - w * z);
+    float r11 = w * w - x * x + y * y - z * z;
+    return q_atan2(-r10, r11);
+}
+
+// utils/transform.py:123-136
+__device__ __forceinline__ void euler2quat(float roll, float pitch, float yaw, float q[4])
+{
+    float sy, cy, sp, cp, sr, cr;
+    q_sincos(yaw * 0.5f, sy, cy);
+    q_sincos(pitch * 0.5f, sp, cp);
+    q_sincos(roll * 0.5f, sr, cr);
+    q[0] = cr * cp * cy - sr * sp * sy;
+    q[1] = sr * cp * cy - cr * sp * sy;
+    q[2] = sr * cp * sy + cr * sp * cy;
+    q[3] = cr * cp * sy + sr * sp * cy;
+}
+
+// Drone.df, dynamics/quadrotor.py:80-113 (R[2,2] == 1, diagonal inertia)
+__device__ __forceinline__ void drone_df(const float s[13], const float u[4], const Par &P, float inv_m, float ds[13])
+{
+    const float *q = s + 6, *w = s + 10;
+    Rot R = quat2rot(q);
+    float Fm = u[0] * inv_m;
+    ds[0] = s[3]; ds[1] = s[4]; ds[2] = s[5];
+    ds[3] = R.r20 * Fm;
+    ds[4] = R.r21 * Fm;
+    ds[5] = Fm - kG;
+    float eq = 1.0f - (q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    float kq = 2.0f * eq;                                   // K_quat * e_quat, :96-97
+    float k0 = -w[0] * q[1] - w[1] * q[2] - w[2] * q[3];    // :98
+    float k1 = w[0] * q[0] - w[1] * q[2] + w[2] * q[3];     // :99
+    float k2 = w[1] * q[0] + w[2] * q[1] - w[0] * q[3];     // :100
+    float k3 = w[2] * q[0] - w[1] * q[1] + w[0] * q[2];     // :101
+    ds[6] = -0.5f * k0 + kq * q[0];
+    ds[7] = -0.5f * k1 + kq * q[1];
+    ds[8] = -0.5f * k2 + kq * q[2];
+    ds[9] = -0.5f * k3 + kq * q[3];
+    // inv(I) (I u[1:] - w x I w), :83,:105
+    float Iw0 = P.Ixx * w[0], Iw1 = P.Iyy * w[1], Iw2 = P.Izz * w[2];
+    float c0 = w[1] * Iw2 - w[2] * Iw1;
+    float c1 = w[2] * Iw0 - w[0] * Iw2;
+    float c2 = w[0] * Iw1 - w[1] * Iw0;
+    ds[10] = u[1] - c0 * q_rcp(P.Ixx);
+    ds[11] = u[2] - c1 * q_rcp(P.Iyy);
+    ds[12] = u[3] - c2 * q_rcp(P.Izz);
+}
+
+// Drone.attitude_limit + write-back, dynamics/quadrotor.py:146-168,:135-138.
+// Sequential overriding ifs == the LAST violated axis wins, each built from the
+// un-clamped other two angles; the final `<=` test cancels an exact tie.
+__device__ __forceinline__ bool attitude_limit(float s[13])
+{
+    float r, p, y;
+    quat2euler(s + 6, r, p, y);
+    float ar = fabsf(r), ap = fabsf(p), ay = fabsf(y);
+    bool a = ar >= kLim85, b = ap >= kLim85, c = ay >= kLim175;
+    bool inside = (ar <= kLim85) && (ap <= kLim85) && (ay <= kLim175);
+    bool over = (a || b || c) && !inside;
+    if (over) {
+        float er = r, ep = p, ey = y;
+        if (c) ey = copysignf(kLim175, y);
+        else if (b) ep = copysignf(kLim85, p);
+        else er = copysignf(kLim85, r);
+        euler2quat(er, ep, ey, s + 6);
+        s[10] = 0.0f; s[11] = 0.0f; s[12] = 0.0f;
+    }
+    return over;
+}
+
+// Drone.u_limit, dynamics/quadrotor.py:171-187 (A :47-50, B :52-54); per-rotor clamp [0, m g]
+__device__ __forceinline__ void u_limit(const float u[4], float mg, float out[4])
+{
+    constexpr float a = 0.5f / kL;
+    float f4 = 0.25f * u[0];
+    float p0 = fminf(fmaxf(f4 - a * u[2], 0.0f), mg);
+    float p1 = fminf(fmaxf(f4 + a * u[1], 0.0f), mg);
+    float p2 = fminf(fmaxf(f4 + a * u[2], 0.0f), mg);
+    float p3 = fminf(fmaxf(f4 - a * u[1], 0.0f), mg);
+    out[0] = (p0 + p1) + (p2 + p3);
+    out[1] = kL * (p1 - p3);
+    out[2] = kL * (p2 - p0);
+    out[3] = u[3];
+}
+
+// Drone.step, dynamics/quadrotor.py:126-144: integrate with the PREVIOUS limited
+// control, clamp attitude, then store the newly limited control.
+template <int INTEG>
+__device__ __forceinline__ bool drone_step(float s[13], float u_prev[4], const float u[4], const Par &P, float dt)
+{
+    float inv_m = q_rcp(P.m);
+    float k1[13];
+    drone_df(s, u_prev, P, inv_m, k1);
+    if (INTEG == 0) {
+        // RK45 over the frozen RHS of Drone.f (:115-124) == explicit Euler
+#pragma unroll
+        for (int i = 0; i < 13; ++i) s[i] = fmaf(dt, k1[i], s[i]);
+    } else {
+        float k2[13], k3[13], k4[13], y[13];
+        float h = 0.5f * dt;
+#pragma unroll
+        for (int i = 0; i < 13; ++i) y[i] = fmaf(h, k1[i], s[i]);
+        drone_df(y, u_prev, P, inv_m, k2);
+#pragma unroll
+        for (int i = 0; i < 13; ++i) y[i] = fmaf(h, k2[i], s[i]);
+        drone_df(y, u_prev, P, inv_m, k3);
+#pragma unroll
+        for (int i = 0; i < 13; ++i) y[i] = fmaf(dt, k3[i], s[i]);
+        drone_df(y, u_prev, P, inv_m, k4);
+        float d6 = dt * (1.0f / 6.0f);
+#pragma unroll
+        for (int i = 0; i < 13; ++i) s[i] = fmaf(d6, (k1[i] + k4[i]) + 2.0f * (k2[i] + k3[i]), s[i]);
+    }
+    bool over = attitude_limit(s);
+    u_limit(u, P.m * kG, u_prev);
+    return over;
+}
+
+// attitude_controller, controller/PIDController.py:52-74 with w_des = (0, 0, wdz)
+__device__ __forceinline__ void attitude_controller(const float qdes[4], float wdz, const float s[13], float M[3])
+{
+    float dr, dp, dy, nr, np_, ny;
+    quat2euler(qdes, dr, dp, dy);
+    quat2euler(s + 6, nr, np_, ny);
+    M[0] = -10.0f * (dr - nr) + 5.1f * (0.0f - s[10]);
+    M[1] = -10.0f * (dp - np_) + 5.1f * (0.0f - s[11]);
+    M[2] = -9.5f * (dy - ny) + 4.0f * (wdz - s[12]);
+}
+
+// shared tail of hover_controller (:84-102) and vel_controller (:116-134):
+// rewrites the desired attitude quaternion in place, returns the thrust.
+__device__ __forceinline__ float desired_attitude(float ax, float ay, float az, float qdes[4], float m)
+{
+    float F = fmaf(m, az, m * kG);
+    float psi = quat2yaw(qdes);
+    float sp, cp;
+    q_sincos(psi, sp, cp);
+    constexpr float inv_g = 1.0f / kG;
+    float phi_des = (ax * sp - ay * cp) * inv_g;
+    float theta_des = (ax * cp + ay * sp) * inv_g;
+    euler2quat(phi_des, theta_des, psi, qdes);
+    return F;
+}
+
+// controller.PID (mode 0, PIDController.py:179-185 -> :76-104) or
+// controller.vel_controller (mode 1, :106-141) on explicit desired pos / vel.
+// dv = state_now.vel - state_last.vel (mode 1; identically 0 inside the envs).
+__device__ __forceinline__ void target_control(int mode, const float pdes[3], const float vdes[3], float qdes[4],
+                                               float wdz, const float s[13], const float dv[3], float m, float u[4])
+{
+    float ax, ay, az;
+    if (mode == 0) {
+        ax = -1.0f * (pdes[0] - s[0]) + -1.65f * (vdes[0] - s[3]);   // :80
+        ay = -1.0f * (pdes[1] - s[1]) + -1.65f * (vdes[1] - s[4]);   // :81
+        az = 50.0f * (pdes[2] - s[2]) + 8.0f * (vdes[2] - s[5]);     // :82
+    } else {
+        ax = -0.7f * (vdes[0] - s[3]);                               // :112 (kd_vx = 0)
+        ay = -0.7f * (vdes[1] - s[4]);                               // :113 (kd_vy = 0)
+        az = 1.0f * (vdes[2] - s[5]) + 0.1f * dv[2];                 // :114
+    }
+    u[0] = desired_attitude(ax, ay, az, qdes, m);
+    attitude_controller(qdes, wdz, s, u + 1);
+}
+
+// dock-port states (dynamics/quadrotor.py:213-224) + state2rel (docking_env.py:257-295).
+// Ports are (+0.1,0,0) on the chaser and (-0.1,0,0) on the target (docking_env.py:38,51).
+__device__ __forceinline__ void rel_obs(const float sc[13], const float st[13], float o[12])
+{
+    Rot A = quat2rot(sc + 6);   // R_I2A
+    Rot B = quat2rot(st + 6);   // R_I2B
+    // port offsets in the world frame: R^T port = port_x * (1, r01, r02)
+    float bc0 = 0.1f, bc1 = 0.1f * A.r01, bc2 = 0.1f * A.r02;
+    float bt0 = -0.1f, bt1 = -0.1f * B.r01, bt2 = -0.1f * B.r02;
+    // (p_t - p_c) first: exact-ish in binary32, then the small offsets
+    o[0] = (st[0] - sc[0]) + (bt0 - bc0);
+    o[1] = (st[1] - sc[1]) + (bt1 - bc1);
+    o[2] = (st[2] - sc[2]) + (bt2 - bc2);
+    // vel = v + w x b
+    float wc0 = sc[10], wc1 = sc[11], wc2 = sc[12];
+    float wt0 = st[10], wt1 = st[11], wt2 = st[12];
+    float cvx = wc1 * bc2 - wc2 * bc1, cvy = wc2 * bc0 - wc0 * bc2, cvz = wc0 * bc1 - wc1 * bc0;
+    float tvx = wt1 * bt2 - wt2 * bt1, tvy = wt2 * bt0 - wt0 * bt2, tvz = wt0 * bt1 - wt1 * bt0;
+    o[3] = (st[3] - sc[3]) + (tvx - cvx);
+    o[4] = (st[4] - sc[4]) + (tvy - cvy);
+    o[5] = (st[5] - sc[5]) + (tvz - cvz);
+    // R_A2B = R_I2B @ R_I2A^T  (:267), unit diagonals folded in
+    float R00 = 1.0f + B.r01 * A.r01 + B.r02 * A.r02;
+    float R01 = A.r10 + B.r01 + B.r02 * A.r12;
+    float R02 = A.r20 + B.r01 * A.r21 + B.r02;
+    float R10 = B.r10 + A.r01 + B.r12 * A.r02;
+    float R11 = B.r10 * A.r10 + 1.0f + B.r12 * A.r12;
+    float R12 = B.r10 * A.r20 + A.r21 + B.r12;
+    float R20 = B.r20 + B.r21 * A.r01 + A.r02;
+    float R21 = B.r20 * A.r10 + B.r21 + A.r12;
+    float R22 = B.r20 * A.r20 + B.r21 * A.r21 + 1.0f;
+    // rot2euler, utils/transform.py:23-46
+    float phi = q_asin(fminf(fmaxf(R12, -1.0f), 1.0f));
+    float psi = q_atan2(-R10, R11);
+    float th = q_atan2(-R02, R22);
+    float theta = (R12 >= 1.0f || R12 < -1.0f) ? 0.0f : th;
+    // R_I2B w_B - R_A2B (R_I2A w_A)   (:277; association is immaterial)
+    float a0 = wc0 + A.r01 * wc1 + A.r02 * wc2;
+    float a1 = A.r10 * wc0 + wc1 + A.r12 * wc2;
+    float a2 = A.r20 * wc0 + A.r21 * wc1 + wc2;
+    float P = (wt0 + B.r01 * wt1 + B.r02 * wt2) - (R00 * a0 + R01 * a1 + R02 * a2);
+    float Q = (B.r10 * wt0 + wt1 + B.r12 * wt2) - (R10 * a0 + R11 * a1 + R12 * a2);
+    float Rr = (B.r20 * wt0 + B.r21 * wt1 + wt2) - (R20 * a0 + R21 * a1 + R22 * a2);
+    float sth, cth, sph, cph;
+    q_sincos(theta, sth, cth);
+    q_sincos(phi, sph, cph);
+    float k = Rr * cth - P * sth;
+    float icph = q_rcp(cph);
+    o[6] = phi; o[7] = theta; o[8] = psi;
+    o[9] = P * cth + Rr * sth;            // :283
+    o[10] = Q - (sph * icph) * k;         // :284
+    o[11] = k * icph;                     // :285
+}
+
+// nominal reset states, docking_env.py:34-57
+__device__ __forceinline__ void nominal_init(float sc[13], float st[13])
+{
+#pragma unroll
+    for (int i = 0; i < 13; ++i) { sc[i] = 0.0f; st[i] = 0.0f; }
+    sc[0] = 8.0f; sc[1] = -50.0f; sc[2] = 5.0f; sc[6] = 1.0f;
+    st[0] = 10.0f; st[1] = -50.0f; st[2] = 5.0f; st[6] = 1.0f;
+}
+
+// (0,1] uniform from 32 random bits: one fused multiply-add, pinned identically in the oracle
+__device__ __forceinline__ float u01(unsigned v) { return __fmaf_rn((float)v, 2.3283064e-10f, 2.3283064e-10f); }
+__device__ __forceinline__ float sym(float u) { return __fmaf_rn(2.0f, u, -1.0f); }
+
+struct RandCfg {
+    uint64_t seed;
+    float rr[8];       // pos, vel, euler, rate half-ranges; mass lo,hi; inertia lo,hi
+    float par_nom[4];  // nominal mass, Ixx, Iyy, Izz
+};
+
+// rocRAND Philox4x32-10 block `blk` of subsequence (stream<<48 | gid)
+__device__ __forceinline__ uint4 philox_block(uint64_t seed, uint64_t stream, uint64_t gid, uint64_t blk)
+{
+    rocrand_state_philox4x32_10 rs;
+    rocrand_init(seed, (stream << 48) | gid, 4ull * blk, &rs);
+    return rocrand4(&rs);
+}
+
+// randomised initial state (+ per-episode params): 16 uniforms = blocks 4*ctr..4*ctr+3.
+// Build extension; the reference's v0/v2 have no randomness.
+__device__ __forceinline__ void random_init(const RandCfg &rc, uint64_t stream, uint64_t gid, uint64_t ctr,
+                                            float sc[13], float st[13], Par &P)
+{
+    uint4 w0 = philox_block(rc.seed, stream, gid, 4ull * ctr + 0);
+    uint4 w1 = philox_block(rc.seed, stream, gid, 4ull * ctr + 1);
+    uint4 w2 = philox_block(rc.seed, stream, gid, 4ull * ctr + 2);
+    uint4 w3 = philox_block(rc.seed, stream, gid, 4ull * ctr + 3);
+    nominal_init(sc, st);
+    sc[0] = __fmaf_rn(sym(u01(w0.x)), rc.rr[0], 8.0f);
+    sc[1] = __fmaf_rn(sym(u01(w0.y)), rc.rr[0], -50.0f);
+    sc[2] = __fmaf_rn(sym(u01(w0.z)), rc.rr[0], 5.0f);
+    sc[3] = sym(u01(w0.w)) * rc.rr[1];
+    sc[4] = sym(u01(w1.x)) * rc.rr[1];
+    sc[5] = sym(u01(w1.y)) * rc.rr[1];
+    float e0 = sym(u01(w1.z)) * rc.rr[2];
+    float e1 = sym(u01(w1.w)) * rc.rr[2];
+    float e2 = sym(u01(w2.x)) * rc.rr[2];
+    euler2quat(e0, e1, e2, sc + 6);
+    sc[10] = sym(u01(w2.y)) * rc.rr[3];
+    sc[11] = sym(u01(w2.z)) * rc.rr[3];
+    sc[12] = sym(u01(w2.w)) * rc.rr[3];
+    P.m = rc.par_nom[0] * __fmaf_rn(rc.rr[5] - rc.rr[4], u01(w3.x), rc.rr[4]);
+    P.Ixx = rc.par_nom[1] * __fmaf_rn(rc.rr[7] - rc.rr[6], u01(w3.y), rc.rr[6]);
+    P.Iyy = rc.par_nom[2] * __fmaf_rn(rc.rr[7] - rc.rr[6], u01(w3.z), rc.rr[6]);
+    P.Izz = rc.par_nom[3] * __fmaf_rn(rc.rr[7] - rc.rr[6], u01(w3.w), rc.rr[6]);
+}
+
+__device__ __forceinline__ void random_action(uint64_t seed, uint64_t gid, uint64_t k, float a[4])
+{
+    uint4 w = philox_block(seed, STREAM_ACTIONS, gid, k);
+    a[0] = sym(u01(w.x)); a[1] = sym(u01(w.y)); a[2] = sym(u01(w.z)); a[3] = sym(u01(w.w));
+}
+
+// per-env registers
+struct Env {
+    float sc[13], st[13], uc[4], ut[4], qd[4], ls, t;
+};
+
+// DockingEnv.step (docking_env.py:104-231) / MovingDockingEnv.step (moving_docking_env.py:111-192)
+template <int INTEG>
+__device__ __forceinline__ void env_step(Env &e, const float a[4], const Par &P, const EnvConst &C, float obs[12],
+                                         float &reward, unsigned &flags)
+{
+    e.t += 1.0f;                                              // :108
+    // chaser command: rotor2control @ (std*a + mean), :115 with :98-99 and quadrotor.py:56-59
+    float mean = 0.5f * P.m * kG;
+    float f0 = fmaf(mean, a[0], mean), f1 = fmaf(mean, a[1], mean);
+    float f2 = fmaf(mean, a[2], mean), f3 = fmaf(mean, a[3], mean);
+    float u_c[4], u_t[4];
+    u_c[0] = (f0 + f1) + (f2 + f3);
+    u_c[1] = kL * (f1 - f3);
+    u_c[2] = kL * (f2 - f0);
+    u_c[3] = kLambda * ((f0 - f1) + (f2 - f3));
+    // target command from the target state BEFORE stepping, :119 / v2 :126
+    const float pdes[3] = {10.0f, -50.0f, 5.0f};              // :60
+    const float vdes[3] = {C.vdes_x, 0.0f, 0.0f};
+    const float dv[3] = {0.0f, 0.0f, 0.0f};                   // state_last aliases state_now (moving_docking_env.py:117)
+    target_control(C.kind, pdes, vdes, e.qd, 0.0f, e.st, dv, P.m, u_t);
+    bool lim_t = drone_step<INTEG>(e.st, e.ut, u_t, P, C.dt); // :120
+    bool lim_c = drone_step<INTEG>(e.sc, e.uc, u_c, P, C.dt); // :121
+    rel_obs(e.sc, e.st, obs);                                 // :124-127
+    float np2 = obs[0] * obs[0] + obs[1] * obs[1] + obs[2] * obs[2];
+    float nv2 = obs[3] * obs[3] + obs[4] * obs[4] + obs[5] * obs[5];
+    float ne2 = obs[6] * obs[6] + obs[7] * obs[7] + obs[8] * obs[8];
+    float nr2 = obs[9] * obs[9] + obs[10] * obs[10] + obs[11] * obs[11];
+    float na2 = a[0] * a[0] + a[1] * a[1] + a[2] * a[2] + a[3] * a[3];
+    float np_ = q_sqrt(np2), nv = q_sqrt(nv2), ne = q_sqrt(ne2), nr = q_sqrt(nr2), na = q_sqrt(na2);
+    bool docked = (np_ < 0.1f) && (nv < 0.1f) && (fabsf(obs[6]) < kLim10) && (fabsf(obs[7]) < kLim10)
+                  && (fabsf(obs[8]) < kLim10);                // :130-134
+    bool over = (np_ >= C.rmax) || (e.sc[2] <= 0.1f);         // :141-142
+    bool overtime = e.t >= kTMax;                             // :152
+    // shaping, :215-219 / v2 :176-180
+    float shaping = -10.0f * np_ * q_rcp(C.rmax) - nv - (10.0f / kPi) * ne - nr - 0.1f * na + (docked ? 1.0f : 0.0f);
+    reward = shaping - e.ls;                                  // :221
+    e.ls = shaping;                                           // :222
+    flags = (docked ? FLAG_DOCKED : 0u) | (over ? FLAG_OVERLIMIT : 0u) | (overtime ? FLAG_OVERTIME : 0u)
+            | (lim_c ? FLAG_CLIM : 0u) | (lim_t ? FLAG_TLIM : 0u);
+}
+
+// DockingEnv.reset (docking_env.py:233-244) + Drone.reset (quadrotor.py:65-78):
+// new initial states, stored controls, t and last_shaping zeroed, q_des untouched.
+__device__ __forceinline__ void env_reset(Env &e, const float ic[13], const float it[13], float obs[12])
+{
+#pragma unroll
+    for (int i = 0; i < 13; ++i) { e.sc[i] = ic[i]; e.st[i] = it[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { e.uc[i] = 0.0f; e.ut[i] = 0.0f; }
+    e.ls = 0.0f;
+    e.t = 0.0f;
+    rel_obs(e.sc, e.st, obs);
+}
+
+}  // namespace qs

@@ -1,0 +1,897 @@
+// quadsim_hip.hip -- kernels + C ABI of libquadsim_hip.so (gfx950 only).
+//
+// HBM layout of the persistent env state: AoSoA tiles of 64 envs (one
+// wavefront).  Tile k holds kRecWords (40) field rows of 64 floats:
+//     st[(k*40 + f)*64 + lane]
+// so every field access of a wave is one fully coalesced 256-B segment and a
+// tile is one contiguous 10 KiB block.  Per-env params (mass, Ixx, Iyy, Izz)
+// live in a parallel [tile][4][64] array that is only read when the handle
+// uses per-env params.  API-facing buffers keep the reference's row-major
+// shapes ([N,4] actions, [N,12] obs, ...).
+//
+// See include/quadsim.h for the contract of each entry point and the reference
+// file:line it replaces.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/quadsim.h"
+#include "quadsim_device.hpp"
+
+using namespace qs;
+
+namespace {
+
+constexpr int kBlock = 256;  // 4 wavefronts = 4 tiles per workgroup
+
+struct StepArgs {
+    float *st;             // [tiles][40][64]
+    float *par;            // [tiles][4][64]
+    const float *actions;  // [N,4] (step) / [T,N,4] (rollout) / nullptr (in-kernel random)
+    float *obs;            // [N,12] / [T,N,12]
+    float *reward;         // [N] / [T,N]
+    uint8_t *done;
+    uint8_t *flags;        // nullable
+    float *term_obs;       // nullable, [N,12]
+    int64_t n;
+    int64_t T;             // rollout length (1 for step)
+    uint64_t step_idx;     // global step counter of the first step
+    uint64_t gid0;         // global id of env 0
+    EnvConst C;
+    RandCfg rc;
+    Par par_nom;
+    int auto_reset;
+    int randomise;
+};
+
+__device__ __forceinline__ void load_env(const float *__restrict__ st, int64_t tile, int lane, Env &e)
+{
+    const float *b = st + tile * (int64_t)(kRecWords * kTile) + lane;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) e.sc[i] = b[(F_SC + i) * kTile];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) e.st[i] = b[(F_ST + i) * kTile];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e.uc[i] = b[(F_UC + i) * kTile];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e.ut[i] = b[(F_UT + i) * kTile];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e.qd[i] = b[(F_QD + i) * kTile];
+    e.ls = b[F_LS * kTile];
+    e.t = b[F_T * kTile];
+}
+
+__device__ __forceinline__ void store_env(float *__restrict__ st, int64_t tile, int lane, const Env &e)
+{
+    float *b = st + tile * (int64_t)(kRecWords * kTile) + lane;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) b[(F_SC + i) * kTile] = e.sc[i];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) b[(F_ST + i) * kTile] = e.st[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[(F_UC + i) * kTile] = e.uc[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[(F_UT + i) * kTile] = e.ut[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[(F_QD + i) * kTile] = e.qd[i];
+    b[F_LS * kTile] = e.ls;
+    b[F_T * kTile] = e.t;
+}
+
+__device__ __forceinline__ Par load_par(const float *__restrict__ par, int64_t tile, int lane)
+{
+    const float *b = par + tile * (int64_t)(kParWords * kTile) + lane;
+    Par P;
+    P.m = b[0]; P.Ixx = b[kTile]; P.Iyy = b[2 * kTile]; P.Izz = b[3 * kTile];
+    return P;
+}
+
+__device__ __forceinline__ void store_par(float *__restrict__ par, int64_t tile, int lane, const Par &P)
+{
+    float *b = par + tile * (int64_t)(kParWords * kTile) + lane;
+    b[0] = P.m; b[kTile] = P.Ixx; b[2 * kTile] = P.Iyy; b[3 * kTile] = P.Izz;
+}
+
+__device__ __forceinline__ void store_obs(float *__restrict__ obs, int64_t env, const float o[12])
+{
+    float4 *p = reinterpret_cast<float4 *>(obs + env * 12);
+    p[0] = make_float4(o[0], o[1], o[2], o[3]);
+    p[1] = make_float4(o[4], o[5], o[6], o[7]);
+    p[2] = make_float4(o[8], o[9], o[10], o[11]);
+}
+
+// one env.step for the lane's env + VecEnv auto-reset; shared by step and rollout kernels
+template <int INTEG, bool PARAMS>
+__device__ __forceinline__ void step_and_maybe_reset(Env &e, Par &P, const float a[4], const StepArgs &A, int64_t env,
+                                                     uint64_t k, float obs[12], float &reward, unsigned &flags,
+                                                     bool &done, bool write_term)
+{
+    env_step<INTEG>(e, a, P, A.C, obs, reward, flags);
+    done = (flags & (FLAG_OVERLIMIT | FLAG_OVERTIME)) != 0;
+    if (done && A.auto_reset) {
+        if (write_term && A.term_obs) store_obs(A.term_obs, env, obs);
+        float ic[13], it[13];
+        if (A.randomise) {
+            Par Pn;
+            random_init(A.rc, STREAM_AUTORESET, A.gid0 + (uint64_t)env, k + 1, ic, it, Pn);
+            if (PARAMS && A.randomise >= 2) P = Pn;
+        } else {
+            nominal_init(ic, it);
+        }
+        env_reset(e, ic, it, obs);
+    }
+}
+
+// K1: one fused env.step for N envs (DockingEnv.step, docking_env.py:104-231)
+template <int INTEG, bool PARAMS>
+__global__ __launch_bounds__(kBlock) void k_step(StepArgs A)
+{
+    const int lane = threadIdx.x & (kTile - 1);
+    const int64_t tile = (int64_t)blockIdx.x * (kBlock / kTile) + (threadIdx.x >> 6);
+    const int64_t env = tile * kTile + lane;
+    if (env >= A.n) return;
+    Env e;
+    load_env(A.st, tile, lane, e);
+    Par P = A.par_nom;
+    if (PARAMS) P = load_par(A.par, tile, lane);
+    const float4 av = reinterpret_cast<const float4 *>(A.actions)[env];
+    const float a[4] = {av.x, av.y, av.z, av.w};
+    float obs[12], reward;
+    unsigned flags;
+    bool done;
+    step_and_maybe_reset<INTEG, PARAMS>(e, P, a, A, env, A.step_idx, obs, reward, flags, done, true);
+    store_env(A.st, tile, lane, e);
+    if (PARAMS && A.randomise >= 2 && done && A.auto_reset) store_par(A.par, tile, lane, P);
+    store_obs(A.obs, env, obs);
+    A.reward[env] = reward;
+    A.done[env] = done ? 1 : 0;
+    if (A.flags) A.flags[env] = (uint8_t)flags;
+}
+
+// K4: T steps per launch, env state in registers (Runner loop, rl_baselines/ppo2/ppo2.py:472-499)
+template <int INTEG, bool PARAMS>
+__global__ __launch_bounds__(kBlock) void k_rollout(StepArgs A)
+{
+    const int lane = threadIdx.x & (kTile - 1);
+    const int64_t tile = (int64_t)blockIdx.x * (kBlock / kTile) + (threadIdx.x >> 6);
+    const int64_t env = tile * kTile + lane;
+    if (env >= A.n) return;
+    Env e;
+    load_env(A.st, tile, lane, e);
+    Par P = A.par_nom;
+    if (PARAMS) P = load_par(A.par, tile, lane);
+    for (int64_t t = 0; t < A.T; ++t) {
+        const uint64_t k = A.step_idx + (uint64_t)t;
+        float a[4];
+        if (A.actions) {
+            const float4 av = reinterpret_cast<const float4 *>(A.actions)[t * A.n + env];
+            a[0] = av.x; a[1] = av.y; a[2] = av.z; a[3] = av.w;
+        } else {
+            random_action(A.rc.seed, A.gid0 + (uint64_t)env, k, a);
+        }
+        float obs[12], reward;
+        unsigned flags;
+        bool done;
+        step_and_maybe_reset<INTEG, PARAMS>(e, P, a, A, env, k, obs, reward, flags, done, false);
+        const int64_t o = t * A.n + env;
+        store_obs(A.obs, o, obs);
+        A.reward[o] = reward;
+        A.done[o] = done ? 1 : 0;
+        if (A.flags) A.flags[o] = (uint8_t)flags;
+    }
+    store_env(A.st, tile, lane, e);
+    if (PARAMS && A.randomise >= 2) store_par(A.par, tile, lane, P);
+}
+
+// K2: masked reset (DockingEnv.reset, docking_env.py:233-244); init_all also rewrites q_des, like __init__
+__global__ __launch_bounds__(kBlock) void k_reset(StepArgs A, const uint8_t *__restrict__ mask, int init_all)
+{
+    const int lane = threadIdx.x & (kTile - 1);
+    const int64_t tile = (int64_t)blockIdx.x * (kBlock / kTile) + (threadIdx.x >> 6);
+    const int64_t env = tile * kTile + lane;
+    if (env >= A.n) return;
+    if (mask && !mask[env]) return;
+    Env e;
+    load_env(A.st, tile, lane, e);
+    float ic[13], it[13], obs[12];
+    if (A.randomise) {
+        Par Pn;
+        random_init(A.rc, STREAM_RESET, A.gid0 + (uint64_t)env, A.step_idx, ic, it, Pn);
+        if (A.randomise >= 2) store_par(A.par, tile, lane, Pn);
+    } else {
+        nominal_init(ic, it);
+    }
+    if (init_all) { e.qd[0] = 1.0f; e.qd[1] = 0.0f; e.qd[2] = 0.0f; e.qd[3] = 0.0f; }
+    env_reset(e, ic, it, obs);
+    store_env(A.st, tile, lane, e);
+    if (A.obs) store_obs(A.obs, env, obs);
+}
+
+__global__ __launch_bounds__(kBlock) void k_fill_par(float *par, int64_t n, Par P)
+{
+    const int lane = threadIdx.x & (kTile - 1);
+    const int64_t tile = (int64_t)blockIdx.x * (kBlock / kTile) + (threadIdx.x >> 6);
+    if (tile * kTile + lane >= n) return;
+    store_par(par, tile, lane, P);
+}
+
+__global__ __launch_bounds__(kBlock) void k_fill_actions(float *__restrict__ actions, int64_t n, int64_t T, uint64_t seed,
+                                                         uint64_t gid0, uint64_t step0)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n * T) return;
+    const int64_t t = i / n, env = i - t * n;
+    float a[4];
+    random_action(seed, gid0 + (uint64_t)env, step0 + (uint64_t)t, a);
+    reinterpret_cast<float4 *>(actions)[i] = make_float4(a[0], a[1], a[2], a[3]);
+}
+
+// AoS <-> AoSoA conversion for qs_get_state / qs_set_state / params
+struct StateIO {
+    float *chaser, *target, *u_prev, *qdes, *ls, *t;
+};
+template <bool TO_USER>
+__global__ __launch_bounds__(kBlock) void k_state_io(float *st, int64_t n, StateIO io)
+{
+    const int lane = threadIdx.x & (kTile - 1);
+    const int64_t tile = (int64_t)blockIdx.x * (kBlock / kTile) + (threadIdx.x >> 6);
+    const int64_t env = tile * kTile + lane;
+    if (env >= n) return;
+    float *b = st + tile * (int64_t)(kRecWords * kTile) + lane;
+    auto mv = [&](float *user, int f) {
+        if (!user) return;
+        if (TO_USER) *user = b[f * kTile];
+        else b[f * kTile] = *user;
+    };
+    for (int i = 0; i < 13; ++i) mv(io.chaser ? io.chaser + env * 13 + i : nullptr, F_SC + i);
+    for (int i = 0; i < 13; ++i) mv(io.target ? io.target + env * 13 + i : nullptr, F_ST + i);
+    for (int i = 0; i < 8; ++i) mv(io.u_prev ? io.u_prev + env * 8 + i : nullptr, F_UC + i);
+    for (int i = 0; i < 4; ++i) mv(io.qdes ? io.qdes + env * 4 + i : nullptr, F_QD + i);
+    mv(io.ls ? io.ls + env : nullptr, F_LS);
+    mv(io.t ? io.t + env : nullptr, F_T);
+}
+
+template <bool TO_USER>
+__global__ __launch_bounds__(kBlock) void k_par_io(float *par, int64_t n, float *mass, float *inertia)
+{
+    const int lane = threadIdx.x & (kTile - 1);
+    const int64_t tile = (int64_t)blockIdx.x * (kBlock / kTile) + (threadIdx.x >> 6);
+    const int64_t env = tile * kTile + lane;
+    if (env >= n) return;
+    float *b = par + tile * (int64_t)(kParWords * kTile) + lane;
+    if (TO_USER) {
+        if (mass) mass[env] = b[0];
+        if (inertia) for (int i = 0; i < 3; ++i) inertia[env * 3 + i] = b[(1 + i) * kTile];
+    } else {
+        if (mass) b[0] = mass[env];
+        if (inertia) for (int i = 0; i < 3; ++i) b[(1 + i) * kTile] = inertia[env * 3 + i];
+    }
+}
+
+// ---- layer-1 kernels on row-major user arrays ------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_drone_step(int64_t n, float *state, float *u_prev, const float *u,
+                                                       const float *par, uint8_t *limited, Par par_nom, float dt,
+                                                       int integ)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float s[13], up[4], uu[4];
+    for (int j = 0; j < 13; ++j) s[j] = state[i * 13 + j];
+    for (int j = 0; j < 4; ++j) { up[j] = u_prev[i * 4 + j]; uu[j] = u[i * 4 + j]; }
+    Par P = par_nom;
+    if (par) { P.m = par[i * 4]; P.Ixx = par[i * 4 + 1]; P.Iyy = par[i * 4 + 2]; P.Izz = par[i * 4 + 3]; }
+    bool over = integ == 0 ? drone_step<0>(s, up, uu, P, dt) : drone_step<1>(s, up, uu, P, dt);
+    for (int j = 0; j < 13; ++j) state[i * 13 + j] = s[j];
+    for (int j = 0; j < 4; ++j) u_prev[i * 4 + j] = up[j];
+    if (limited) limited[i] = over ? 1 : 0;
+}
+
+__global__ __launch_bounds__(kBlock) void k_ctrl(int64_t n, int mode, float *state_des, const float *state,
+                                                 const float *state_last, float mass, float *u_out)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float sd[13], s[13], dv[3] = {0.0f, 0.0f, 0.0f}, u[4];
+    for (int j = 0; j < 13; ++j) { sd[j] = state_des[i * 13 + j]; s[j] = state[i * 13 + j]; }
+    if (mode == 1 && state_last) for (int j = 0; j < 3; ++j) dv[j] = s[3 + j] - state_last[i * 13 + 3 + j];
+    target_control(mode, sd, sd + 3, sd + 6, sd[12], s, dv, mass, u);
+    for (int j = 0; j < 4; ++j) { state_des[i * 13 + 6 + j] = sd[6 + j]; u_out[i * 4 + j] = u[j]; }
+    state_des[i * 13 + 10] = 0.0f;   // roll_rate_des,  PIDController.py:101
+    state_des[i * 13 + 11] = 0.0f;   // pitch_rate_des, PIDController.py:102
+}
+
+__global__ __launch_bounds__(kBlock) void k_rel_obs(int64_t n, const float *chaser, const float *target, float *obs)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    float sc[13], st[13], o[12];
+    for (int j = 0; j < 13; ++j) { sc[j] = chaser[i * 13 + j]; st[j] = target[i * 13 + j]; }
+    rel_obs(sc, st, o);
+    for (int j = 0; j < 12; ++j) obs[i * 12 + j] = o[j];
+}
+
+// ---------------------------------------------------------------------------------------------
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e_ = (expr);                                                                     \
+        if (e_ != hipSuccess) return fail(QS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+struct DeviceGuard {
+    int prev = -1;
+    bool ok = true;
+    explicit DeviceGuard(int dev)
+    {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) ok = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceGuard()
+    {
+        if (prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+inline int64_t tiles_of(int64_t n) { return (n + kTile - 1) / kTile; }
+inline unsigned grid_tiles(int64_t n) { return (unsigned)((tiles_of(n) + (kBlock / kTile) - 1) / (kBlock / kTile)); }
+inline unsigned grid_flat(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlock); }
+
+}  // namespace
+
+struct QsEnv {
+    QsConfig cfg;
+    int64_t n = 0, tiles = 0;
+    float *st = nullptr, *par = nullptr;
+    bool per_env_params = false;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    uint64_t step = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    // staging for QS_IO_HOST
+    void *stage = nullptr;
+    size_t stage_bytes = 0;
+};
+
+namespace {
+
+StepArgs make_args(const QsEnv *e)
+{
+    StepArgs A;
+    memset(&A, 0, sizeof A);
+    A.st = e->st;
+    A.par = e->par;
+    A.n = e->n;
+    A.T = 1;
+    A.step_idx = e->step;
+    A.gid0 = e->cfg.env_id_offset;
+    A.C.kind = e->cfg.kind;
+    A.C.dt = e->cfg.dt;
+    A.C.rmax = e->cfg.kind == QS_KIND_DOCKING_V0 ? 3.0f : 10.0f;
+    A.C.vdes_x = e->cfg.kind == QS_KIND_DOCKING_V0 ? 0.0f : 0.2f;
+    A.rc.seed = e->cfg.seed;
+    for (int i = 0; i < 4; ++i) A.rc.rr[i] = e->cfg.init_range[i];
+    A.rc.rr[4] = e->cfg.mass_scale[0]; A.rc.rr[5] = e->cfg.mass_scale[1];
+    A.rc.rr[6] = e->cfg.inertia_scale[0]; A.rc.rr[7] = e->cfg.inertia_scale[1];
+    A.rc.par_nom[0] = e->cfg.mass;
+    for (int i = 0; i < 3; ++i) A.rc.par_nom[1 + i] = e->cfg.inertia[i];
+    A.par_nom = Par{e->cfg.mass, e->cfg.inertia[0], e->cfg.inertia[1], e->cfg.inertia[2]};
+    A.auto_reset = e->cfg.auto_reset;
+    A.randomise = e->cfg.randomise;
+    return A;
+}
+
+int ensure_stage(QsEnv *e, size_t bytes)
+{
+    if (e->stage_bytes >= bytes) return QS_OK;
+    if (e->stage) { HIP_TRY(hipStreamSynchronize(e->stream)); HIP_TRY(hipFree(e->stage)); e->stage = nullptr; e->stage_bytes = 0; }
+    HIP_TRY(hipMalloc(&e->stage, bytes));
+    e->stage_bytes = bytes;
+    return QS_OK;
+}
+
+// bump allocator over the staging buffer (256-B aligned slices)
+struct Stage {
+    char *base;
+    size_t off = 0;
+    template <typename T> T *take(size_t count)
+    {
+        T *p = reinterpret_cast<T *>(base + off);
+        off += (count * sizeof(T) + 255) & ~size_t(255);
+        return p;
+    }
+};
+
+template <typename K>
+void launch_by_variant(K &&fn, int integ, bool params)
+{
+    if (integ == QS_INTEG_FROZEN) { if (params) fn.template operator()<0, true>(); else fn.template operator()<0, false>(); }
+    else { if (params) fn.template operator()<1, true>(); else fn.template operator()<1, false>(); }
+}
+
+int launch_step(QsEnv *e, StepArgs &A)
+{
+    const unsigned grid = grid_tiles(e->n);
+    hipStream_t s = e->stream;
+    auto fn = [&]<int INTEG, bool PARAMS>() { hipLaunchKernelGGL((k_step<INTEG, PARAMS>), dim3(grid), dim3(kBlock), 0, s, A); };
+    launch_by_variant(fn, e->cfg.integrator, e->per_env_params);
+    HIP_TRY(hipGetLastError());
+    return QS_OK;
+}
+
+int launch_rollout(QsEnv *e, StepArgs &A)
+{
+    const unsigned grid = grid_tiles(e->n);
+    hipStream_t s = e->stream;
+    auto fn = [&]<int INTEG, bool PARAMS>() { hipLaunchKernelGGL((k_rollout<INTEG, PARAMS>), dim3(grid), dim3(kBlock), 0, s, A); };
+    launch_by_variant(fn, e->cfg.integrator, e->per_env_params);
+    HIP_TRY(hipGetLastError());
+    return QS_OK;
+}
+
+int fill_params(QsEnv *e)
+{
+    Par P{e->cfg.mass, e->cfg.inertia[0], e->cfg.inertia[1], e->cfg.inertia[2]};
+    hipLaunchKernelGGL(k_fill_par, dim3(grid_tiles(e->n)), dim3(kBlock), 0, e->stream, e->par, e->n, P);
+    HIP_TRY(hipGetLastError());
+    return QS_OK;
+}
+
+int do_reset(QsEnv *e, const uint8_t *d_mask, float *d_obs, int init_all)
+{
+    StepArgs A = make_args(e);
+    A.obs = d_obs;
+    hipLaunchKernelGGL(k_reset, dim3(grid_tiles(e->n)), dim3(kBlock), 0, e->stream, A, d_mask, init_all);
+    HIP_TRY(hipGetLastError());
+    return QS_OK;
+}
+
+#define CHECK_ENV(e)                                                   \
+    if (!(e)) return fail(QS_ERR_INVALID, "%s: null handle", __func__); \
+    DeviceGuard guard_((e)->cfg.device);                               \
+    if (!guard_.ok) return fail(QS_ERR_HIP, "%s: hipSetDevice(%d) failed", __func__, (e)->cfg.device)
+
+}  // namespace
+
+extern "C" {
+
+int qs_version(void) { return QS_VERSION; }
+const char *qs_last_error(void) { return g_err; }
+
+int qs_config_default(QsConfig *cfg)
+{
+    if (!cfg) return fail(QS_ERR_INVALID, "qs_config_default: null cfg");
+    memset(cfg, 0, sizeof *cfg);
+    cfg->struct_size = (int32_t)sizeof(QsConfig);
+    cfg->kind = QS_KIND_DOCKING_V0;
+    cfg->num_envs = 1;
+    cfg->device = 0;
+    cfg->integrator = QS_INTEG_FROZEN;
+    cfg->dt = 0.02f;
+    cfg->auto_reset = 0;
+    cfg->randomise = QS_RANDOMISE_NONE;
+    cfg->io_space = QS_IO_DEVICE;
+    cfg->seed = 0;
+    cfg->env_id_offset = 0;
+    cfg->mass_scale[0] = cfg->mass_scale[1] = 1.0f;
+    cfg->inertia_scale[0] = cfg->inertia_scale[1] = 1.0f;
+    cfg->mass = 0.18f;
+    cfg->inertia[0] = 0.00025f; cfg->inertia[1] = 0.000232f; cfg->inertia[2] = 0.0003738f;
+    cfg->stream = nullptr;
+    cfg->external_stream = 0;
+    return QS_OK;
+}
+
+int qs_create(const QsConfig *cfg, QsEnv **out)
+{
+    if (!cfg || !out) return fail(QS_ERR_INVALID, "qs_create: null argument");
+    *out = nullptr;
+    if (cfg->struct_size != (int32_t)sizeof(QsConfig))
+        return fail(QS_ERR_INVALID, "qs_create: QsConfig size mismatch (got %d, want %zu)", cfg->struct_size, sizeof(QsConfig));
+    if (cfg->num_envs < 1) return fail(QS_ERR_INVALID, "qs_create: num_envs must be >= 1");
+    if (cfg->num_envs > ((int64_t)1 << 31)) return fail(QS_ERR_INVALID, "qs_create: num_envs too large");
+    if (cfg->kind != QS_KIND_DOCKING_V0 && cfg->kind != QS_KIND_DOCKING_V2) return fail(QS_ERR_INVALID, "qs_create: unknown env kind %d", cfg->kind);
+    if (cfg->integrator != QS_INTEG_FROZEN && cfg->integrator != QS_INTEG_RK4) return fail(QS_ERR_INVALID, "qs_create: unknown integrator %d", cfg->integrator);
+    if (cfg->randomise < 0 || cfg->randomise > 2) return fail(QS_ERR_INVALID, "qs_create: randomise must be 0..2");
+    if (cfg->io_space != QS_IO_DEVICE && cfg->io_space != QS_IO_HOST) return fail(QS_ERR_INVALID, "qs_create: bad io_space");
+    if (!(cfg->dt > 0.0f) || !(cfg->mass > 0.0f) || !(cfg->inertia[0] > 0.0f) || !(cfg->inertia[1] > 0.0f) || !(cfg->inertia[2] > 0.0f))
+        return fail(QS_ERR_INVALID, "qs_create: dt, mass and inertia must be positive");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(QS_ERR_NO_DEVICE, "qs_create: no HIP device visible (this library has no CPU fallback)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(QS_ERR_INVALID, "qs_create: device %d out of range (%d visible)", cfg->device, ndev);
+    DeviceGuard guard(cfg->device);
+    if (!guard.ok) return fail(QS_ERR_HIP, "qs_create: hipSetDevice(%d) failed", cfg->device);
+
+    QsEnv *e = new (std::nothrow) QsEnv();
+    if (!e) return fail(QS_ERR_NOMEM, "qs_create: out of host memory");
+    e->cfg = *cfg;
+    e->n = cfg->num_envs;
+    e->tiles = tiles_of(e->n);
+    e->per_env_params = cfg->randomise >= QS_RANDOMISE_PARAMS;
+    int rc = QS_OK;
+    auto body = [&]() -> int {
+        if (cfg->external_stream) e->stream = (hipStream_t)cfg->stream;
+        else { HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)); e->own_stream = true; }
+        HIP_TRY(hipEventCreate(&e->ev0));
+        HIP_TRY(hipEventCreate(&e->ev1));
+        const size_t st_bytes = (size_t)e->tiles * kRecWords * kTile * sizeof(float);
+        const size_t par_bytes = (size_t)e->tiles * kParWords * kTile * sizeof(float);
+        HIP_TRY(hipMalloc((void **)&e->st, st_bytes));
+        HIP_TRY(hipMalloc((void **)&e->par, par_bytes));
+        HIP_TRY(hipMemsetAsync(e->st, 0, st_bytes, e->stream));
+        HIP_TRY(hipMemsetAsync(e->par, 0, par_bytes, e->stream));
+        int r = fill_params(e);
+        if (r) return r;
+        // __init__: nominal states, q_des = identity; never randomised (randomisation starts at the first reset)
+        StepArgs A = make_args(e);
+        A.randomise = 0;
+        hipLaunchKernelGGL(k_reset, dim3(grid_tiles(e->n)), dim3(kBlock), 0, e->stream, A, (const uint8_t *)nullptr, 1);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        return QS_OK;
+    };
+    rc = body();
+    if (rc != QS_OK) { qs_destroy(e); return rc; }
+    *out = e;
+    return QS_OK;
+}
+
+int qs_destroy(QsEnv *e)
+{
+    if (!e) return QS_OK;
+    DeviceGuard guard(e->cfg.device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    if (e->st) (void)hipFree(e->st);
+    if (e->par) (void)hipFree(e->par);
+    if (e->stage) (void)hipFree(e->stage);
+    if (e->ev0) (void)hipEventDestroy(e->ev0);
+    if (e->ev1) (void)hipEventDestroy(e->ev1);
+    if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+    return QS_OK;
+}
+
+int qs_set_stream(QsEnv *e, void *hip_stream, int32_t external)
+{
+    CHECK_ENV(e);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    if (e->own_stream) { HIP_TRY(hipStreamDestroy(e->stream)); e->own_stream = false; }
+    if (external) e->stream = (hipStream_t)hip_stream;
+    else { HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)); e->own_stream = true; }
+    return QS_OK;
+}
+
+int qs_sync(QsEnv *e)
+{
+    CHECK_ENV(e);
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return QS_OK;
+}
+
+int qs_timer_start(QsEnv *e)
+{
+    CHECK_ENV(e);
+    HIP_TRY(hipEventRecord(e->ev0, e->stream));
+    return QS_OK;
+}
+
+int qs_timer_stop(QsEnv *e, float *ms)
+{
+    CHECK_ENV(e);
+    if (!ms) return fail(QS_ERR_INVALID, "qs_timer_stop: null output");
+    HIP_TRY(hipEventRecord(e->ev1, e->stream));
+    HIP_TRY(hipEventSynchronize(e->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, e->ev0, e->ev1));
+    return QS_OK;
+}
+
+int qs_get_step_counter(QsEnv *e, uint64_t *k)
+{
+    if (!e || !k) return fail(QS_ERR_INVALID, "qs_get_step_counter: null argument");
+    *k = e->step;
+    return QS_OK;
+}
+
+int qs_set_step_counter(QsEnv *e, uint64_t k)
+{
+    if (!e) return fail(QS_ERR_INVALID, "qs_set_step_counter: null handle");
+    e->step = k;
+    return QS_OK;
+}
+
+int qs_reset(QsEnv *e, const uint8_t *mask, float *obs_out)
+{
+    CHECK_ENV(e);
+    const int64_t n = e->n;
+    if (e->cfg.io_space == QS_IO_DEVICE) return do_reset(e, mask, obs_out, 0);
+    int r = ensure_stage(e, (size_t)n * (12 * 4 + 1) + 1024);
+    if (r) return r;
+    Stage S{(char *)e->stage};
+    float *d_obs = S.take<float>(n * 12);
+    uint8_t *d_mask = S.take<uint8_t>(n);
+    if (mask) HIP_TRY(hipMemcpyAsync(d_mask, mask, n, hipMemcpyHostToDevice, e->stream));
+    if (obs_out && mask) HIP_TRY(hipMemcpyAsync(d_obs, obs_out, n * 12 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    r = do_reset(e, mask ? d_mask : nullptr, d_obs, 0);
+    if (r) return r;
+    if (obs_out) HIP_TRY(hipMemcpyAsync(obs_out, d_obs, n * 12 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return QS_OK;
+}
+
+int qs_step(QsEnv *e, const float *actions, float *obs, float *reward, uint8_t *done, uint8_t *flags, float *terminal_obs)
+{
+    CHECK_ENV(e);
+    if (!actions || !obs || !reward || !done) return fail(QS_ERR_INVALID, "qs_step: actions, obs, reward and done are required");
+    const int64_t n = e->n;
+    StepArgs A = make_args(e);
+    int r;
+    if (e->cfg.io_space == QS_IO_DEVICE) {
+        A.actions = actions; A.obs = obs; A.reward = reward; A.done = done; A.flags = flags; A.term_obs = terminal_obs;
+        r = launch_step(e, A);
+        if (r) return r;
+    } else {
+        r = ensure_stage(e, (size_t)n * (4 * 4 + 12 * 4 + 4 + 1 + 1 + 12 * 4) + 4096);
+        if (r) return r;
+        Stage S{(char *)e->stage};
+        float *d_act = S.take<float>(n * 4), *d_obs = S.take<float>(n * 12), *d_rew = S.take<float>(n);
+        uint8_t *d_done = S.take<uint8_t>(n), *d_flags = S.take<uint8_t>(n);
+        float *d_term = S.take<float>(n * 12);
+        HIP_TRY(hipMemcpyAsync(d_act, actions, n * 4 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        if (terminal_obs) HIP_TRY(hipMemcpyAsync(d_term, terminal_obs, n * 12 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        A.actions = d_act; A.obs = d_obs; A.reward = d_rew; A.done = d_done; A.flags = d_flags;
+        A.term_obs = terminal_obs ? d_term : nullptr;
+        r = launch_step(e, A);
+        if (r) return r;
+        HIP_TRY(hipMemcpyAsync(obs, d_obs, n * 12 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(reward, d_rew, n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(done, d_done, n, hipMemcpyDeviceToHost, e->stream));
+        if (flags) HIP_TRY(hipMemcpyAsync(flags, d_flags, n, hipMemcpyDeviceToHost, e->stream));
+        if (terminal_obs) HIP_TRY(hipMemcpyAsync(terminal_obs, d_term, n * 12 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    e->step += 1;
+    return QS_OK;
+}
+
+int qs_rollout(QsEnv *e, int64_t T, const float *actions, float *obs, float *reward, uint8_t *done, uint8_t *flags)
+{
+    CHECK_ENV(e);
+    if (T < 1) return fail(QS_ERR_INVALID, "qs_rollout: T must be >= 1");
+    if (!obs || !reward || !done) return fail(QS_ERR_INVALID, "qs_rollout: obs, reward and done are required");
+    if (!e->cfg.auto_reset) return fail(QS_ERR_INVALID, "qs_rollout: requires auto_reset (a roll-out runs through episode ends)");
+    const int64_t n = e->n, tn = T * n;
+    StepArgs A = make_args(e);
+    A.T = T;
+    int r;
+    if (e->cfg.io_space == QS_IO_DEVICE) {
+        A.actions = actions; A.obs = obs; A.reward = reward; A.done = done; A.flags = flags;
+        r = launch_rollout(e, A);
+        if (r) return r;
+    } else {
+        r = ensure_stage(e, (size_t)tn * (4 * 4 + 12 * 4 + 4 + 1 + 1) + 4096);
+        if (r) return r;
+        Stage S{(char *)e->stage};
+        float *d_act = S.take<float>(tn * 4), *d_obs = S.take<float>(tn * 12), *d_rew = S.take<float>(tn);
+        uint8_t *d_done = S.take<uint8_t>(tn), *d_flags = S.take<uint8_t>(tn);
+        if (actions) HIP_TRY(hipMemcpyAsync(d_act, actions, tn * 4 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        A.actions = actions ? d_act : nullptr; A.obs = d_obs; A.reward = d_rew; A.done = d_done; A.flags = d_flags;
+        r = launch_rollout(e, A);
+        if (r) return r;
+        HIP_TRY(hipMemcpyAsync(obs, d_obs, tn * 12 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(reward, d_rew, tn * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(done, d_done, tn, hipMemcpyDeviceToHost, e->stream));
+        if (flags) HIP_TRY(hipMemcpyAsync(flags, d_flags, tn, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    e->step += (uint64_t)T;
+    return QS_OK;
+}
+
+int qs_fill_random_actions(QsEnv *e, int64_t T, uint64_t step0, float *actions)
+{
+    CHECK_ENV(e);
+    if (T < 1 || !actions) return fail(QS_ERR_INVALID, "qs_fill_random_actions: bad arguments");
+    const int64_t tn = T * e->n;
+    float *d = actions;
+    if (e->cfg.io_space == QS_IO_HOST) {
+        int r = ensure_stage(e, (size_t)tn * 16 + 1024);
+        if (r) return r;
+        d = (float *)e->stage;
+    }
+    hipLaunchKernelGGL(k_fill_actions, dim3(grid_flat(tn)), dim3(kBlock), 0, e->stream, d, e->n, T, e->cfg.seed,
+                       e->cfg.env_id_offset, step0);
+    HIP_TRY(hipGetLastError());
+    if (e->cfg.io_space == QS_IO_HOST) {
+        HIP_TRY(hipMemcpyAsync(actions, d, tn * 16, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    return QS_OK;
+}
+
+static int state_io(QsEnv *e, bool to_user, float *chaser, float *target, float *u_prev, float *qdes, float *ls, float *t)
+{
+    const int64_t n = e->n;
+    const int64_t words[6] = {13, 13, 8, 4, 1, 1};
+    float *user[6] = {chaser, target, u_prev, qdes, ls, t};
+    StateIO io{chaser, target, u_prev, qdes, ls, t};
+    float *dev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    if (e->cfg.io_space == QS_IO_HOST) {
+        int r = ensure_stage(e, (size_t)n * 40 * 4 + 4096);
+        if (r) return r;
+        Stage S{(char *)e->stage};
+        for (int i = 0; i < 6; ++i) {
+            dev[i] = S.take<float>(n * words[i]);
+            if (user[i] && !to_user) HIP_TRY(hipMemcpyAsync(dev[i], user[i], n * words[i] * 4, hipMemcpyHostToDevice, e->stream));
+        }
+        io = StateIO{chaser ? dev[0] : nullptr, target ? dev[1] : nullptr, u_prev ? dev[2] : nullptr,
+                     qdes ? dev[3] : nullptr, ls ? dev[4] : nullptr, t ? dev[5] : nullptr};
+    }
+    if (to_user) hipLaunchKernelGGL(k_state_io<true>, dim3(grid_tiles(n)), dim3(kBlock), 0, e->stream, e->st, n, io);
+    else hipLaunchKernelGGL(k_state_io<false>, dim3(grid_tiles(n)), dim3(kBlock), 0, e->stream, e->st, n, io);
+    HIP_TRY(hipGetLastError());
+    if (e->cfg.io_space == QS_IO_HOST) {
+        if (to_user)
+            for (int i = 0; i < 6; ++i)
+                if (user[i]) HIP_TRY(hipMemcpyAsync(user[i], dev[i], n * words[i] * 4, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    return QS_OK;
+}
+
+int qs_get_state(QsEnv *e, float *chaser, float *target, float *u_prev, float *qdes, float *last_shaping, float *t)
+{
+    CHECK_ENV(e);
+    return state_io(e, true, chaser, target, u_prev, qdes, last_shaping, t);
+}
+
+int qs_set_state(QsEnv *e, const float *chaser, const float *target, const float *u_prev, const float *qdes,
+                 const float *last_shaping, const float *t)
+{
+    CHECK_ENV(e);
+    return state_io(e, false, (float *)chaser, (float *)target, (float *)u_prev, (float *)qdes, (float *)last_shaping, (float *)t);
+}
+
+static int par_io(QsEnv *e, bool to_user, float *mass, float *inertia)
+{
+    const int64_t n = e->n;
+    float *dm = mass, *di = inertia;
+    if (e->cfg.io_space == QS_IO_HOST) {
+        int r = ensure_stage(e, (size_t)n * 16 + 1024);
+        if (r) return r;
+        Stage S{(char *)e->stage};
+        dm = S.take<float>(n); di = S.take<float>(n * 3);
+        if (!to_user) {
+            if (mass) HIP_TRY(hipMemcpyAsync(dm, mass, n * 4, hipMemcpyHostToDevice, e->stream));
+            if (inertia) HIP_TRY(hipMemcpyAsync(di, inertia, n * 12, hipMemcpyHostToDevice, e->stream));
+        }
+        if (!mass) dm = nullptr;
+        if (!inertia) di = nullptr;
+    }
+    if (to_user) hipLaunchKernelGGL(k_par_io<true>, dim3(grid_tiles(n)), dim3(kBlock), 0, e->stream, e->par, n, dm, di);
+    else hipLaunchKernelGGL(k_par_io<false>, dim3(grid_tiles(n)), dim3(kBlock), 0, e->stream, e->par, n, dm, di);
+    HIP_TRY(hipGetLastError());
+    if (e->cfg.io_space == QS_IO_HOST) {
+        if (to_user) {
+            if (mass) HIP_TRY(hipMemcpyAsync(mass, dm, n * 4, hipMemcpyDeviceToHost, e->stream));
+            if (inertia) HIP_TRY(hipMemcpyAsync(inertia, di, n * 12, hipMemcpyDeviceToHost, e->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    return QS_OK;
+}
+
+int qs_set_params(QsEnv *e, const float *mass, const float *inertia)
+{
+    CHECK_ENV(e);
+    if (!mass && !inertia) return fail(QS_ERR_INVALID, "qs_set_params: nothing to set");
+    int r = par_io(e, false, (float *)mass, (float *)inertia);
+    if (r) return r;
+    e->per_env_params = true;
+    return QS_OK;
+}
+
+int qs_get_params(QsEnv *e, float *mass, float *inertia)
+{
+    CHECK_ENV(e);
+    return par_io(e, true, mass, inertia);
+}
+
+// ---- layer 1 ---------------------------------------------------------------------------------
+int qs_drone_step(QsEnv *e, int64_t n, float *state, float *u_prev, const float *u, const float *par, uint8_t *limited)
+{
+    CHECK_ENV(e);
+    if (n < 1 || !state || !u_prev || !u) return fail(QS_ERR_INVALID, "qs_drone_step: bad arguments");
+    Par pn{e->cfg.mass, e->cfg.inertia[0], e->cfg.inertia[1], e->cfg.inertia[2]};
+    float *ds = state, *dup = u_prev;
+    const float *du = u, *dp = par;
+    uint8_t *dl = limited;
+    if (e->cfg.io_space == QS_IO_HOST) {
+        int r = ensure_stage(e, (size_t)n * (13 + 4 + 4 + 4) * 4 + n + 4096);
+        if (r) return r;
+        Stage S{(char *)e->stage};
+        float *a = S.take<float>(n * 13), *b = S.take<float>(n * 4), *c = S.take<float>(n * 4), *d = S.take<float>(n * 4);
+        uint8_t *l = S.take<uint8_t>(n);
+        HIP_TRY(hipMemcpyAsync(a, state, n * 52, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(b, u_prev, n * 16, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(c, u, n * 16, hipMemcpyHostToDevice, e->stream));
+        if (par) HIP_TRY(hipMemcpyAsync(d, par, n * 16, hipMemcpyHostToDevice, e->stream));
+        ds = a; dup = b; du = c; dp = par ? d : nullptr; dl = limited ? l : nullptr;
+    }
+    hipLaunchKernelGGL(k_drone_step, dim3(grid_flat(n)), dim3(kBlock), 0, e->stream, n, ds, dup, du, dp, dl, pn, e->cfg.dt,
+                       e->cfg.integrator);
+    HIP_TRY(hipGetLastError());
+    if (e->cfg.io_space == QS_IO_HOST) {
+        HIP_TRY(hipMemcpyAsync(state, ds, n * 52, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(u_prev, dup, n * 16, hipMemcpyDeviceToHost, e->stream));
+        if (limited) HIP_TRY(hipMemcpyAsync(limited, dl, n, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    return QS_OK;
+}
+
+int qs_ctrl(QsEnv *e, int64_t n, int32_t mode, float *state_des, const float *state, const float *state_last, float mass,
+            float *u_out)
+{
+    CHECK_ENV(e);
+    if (n < 1 || !state_des || !state || !u_out || (mode != 0 && mode != 1)) return fail(QS_ERR_INVALID, "qs_ctrl: bad arguments");
+    if (mode == 1 && !state_last) return fail(QS_ERR_INVALID, "qs_ctrl: vel_controller needs state_last");
+    float *dsd = state_des, *duo = u_out;
+    const float *dsn = state, *dsl = state_last;
+    if (e->cfg.io_space == QS_IO_HOST) {
+        int r = ensure_stage(e, (size_t)n * (13 * 3 + 4) * 4 + 4096);
+        if (r) return r;
+        Stage S{(char *)e->stage};
+        float *a = S.take<float>(n * 13), *b = S.take<float>(n * 13), *c = S.take<float>(n * 13), *d = S.take<float>(n * 4);
+        HIP_TRY(hipMemcpyAsync(a, state_des, n * 52, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(b, state, n * 52, hipMemcpyHostToDevice, e->stream));
+        if (state_last) HIP_TRY(hipMemcpyAsync(c, state_last, n * 52, hipMemcpyHostToDevice, e->stream));
+        dsd = a; dsn = b; dsl = state_last ? c : nullptr; duo = d;
+    }
+    hipLaunchKernelGGL(k_ctrl, dim3(grid_flat(n)), dim3(kBlock), 0, e->stream, n, (int)mode, dsd, dsn, dsl, mass, duo);
+    HIP_TRY(hipGetLastError());
+    if (e->cfg.io_space == QS_IO_HOST) {
+        HIP_TRY(hipMemcpyAsync(state_des, dsd, n * 52, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(u_out, duo, n * 16, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    return QS_OK;
+}
+
+int qs_rel_obs(QsEnv *e, int64_t n, const float *chaser, const float *target, float *obs)
+{
+    CHECK_ENV(e);
+    if (n < 1 || !chaser || !target || !obs) return fail(QS_ERR_INVALID, "qs_rel_obs: bad arguments");
+    const float *dc = chaser, *dt = target;
+    float *dob = obs;
+    if (e->cfg.io_space == QS_IO_HOST) {
+        int r = ensure_stage(e, (size_t)n * (13 * 2 + 12) * 4 + 4096);
+        if (r) return r;
+        Stage S{(char *)e->stage};
+        float *a = S.take<float>(n * 13), *b = S.take<float>(n * 13), *c = S.take<float>(n * 12);
+        HIP_TRY(hipMemcpyAsync(a, chaser, n * 52, hipMemcpyHostToDevice, e->stream));
+        HIP_TRY(hipMemcpyAsync(b, target, n * 52, hipMemcpyHostToDevice, e->stream));
+        dc = a; dt = b; dob = c;
+    }
+    hipLaunchKernelGGL(k_rel_obs, dim3(grid_flat(n)), dim3(kBlock), 0, e->stream, n, dc, dt, dob);
+    HIP_TRY(hipGetLastError());
+    if (e->cfg.io_space == QS_IO_HOST) {
+        HIP_TRY(hipMemcpyAsync(obs, dob, n * 48, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    return QS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,313 @@
+"""VecDockingEnv -- N parallel docking-v0 / docking-v2 envs resident on one MI355X.
+
+Host-side mirror of what a trainer sees of the reference: the SB2 ``VecEnv``
+protocol that ``SubprocVecEnv([make_env(...)]*10)`` provides in
+run_docking_ppo2.py:65-67 and whose contract is visible in the in-tree Runner,
+rl_baselines/ppo2/ppo2.py:472-499 (``obs, rewards, dones, infos =
+env.step(clipped_actions)``; auto-reset on done with
+``infos[i]['terminal_observation']``).  All arithmetic happens in the fused HIP
+kernels behind the C ABI (include/quadsim.h); torch is only the owner of the
+device buffers and the stream.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .spaces import Box, docking_spaces
+
+_KINDS = {"docking-v0": _lib.KIND_V0, "docking-v2": _lib.KIND_V2,
+          "gym_docking:docking-v0": _lib.KIND_V0, "gym_docking:docking-v2": _lib.KIND_V2}
+_INTEG = {"frozen": _lib.INTEG_FROZEN, "rk4": _lib.INTEG_RK4}
+
+# chaser initial-state jitter of BASELINE config 3: the ranges commented out at docking_env.py:34-37
+C3_INIT_RANGE = (0.5, 0.1, 0.2, 0.1)
+
+
+def _torch():
+    import torch
+    return torch
+
+
+def shard_range(num_envs_total, rank, world_size):
+    """[start, stop) of the env ids owned by `rank` when envs are partitioned contiguously
+    over `world_size` GPUs (envs are independent: no data-path collective)."""
+    if world_size < 1 or not (0 <= rank < world_size):
+        raise ValueError("bad rank/world_size")
+    base, rem = divmod(int(num_envs_total), world_size)
+    start = rank * base + min(rank, rem)
+    return start, start + base + (1 if rank < rem else 0)
+
+
+class VecDockingEnv:
+    """N envs on one GPU behind the VecEnv protocol.
+
+    backend='torch': actions / obs / rewards / dones are CUDA tensors (zero copy).
+    backend='numpy': host arrays in and out (what SB2 expects); one D2H copy per step.
+    """
+
+    metadata = {"render.modes": ["human"]}
+
+    def __init__(self, env_id="docking-v0", num_envs=1, device=0, integrator="frozen", dt=0.02,
+                 auto_reset=True, randomise=0, seed=0, env_id_offset=0, init_range=(0.0, 0.0, 0.0, 0.0),
+                 mass_scale=(1.0, 1.0), inertia_scale=(1.0, 1.0), mass=0.18,
+                 inertia=(0.00025, 0.000232, 0.0003738), backend="torch", use_torch_stream=True):
+        if env_id not in _KINDS:
+            raise ValueError("unknown env id %r (have %s)" % (env_id, sorted(_KINDS)))
+        if backend not in ("torch", "numpy"):
+            raise ValueError("backend must be 'torch' or 'numpy'")
+        self.env_id = env_id
+        self.kind = _KINDS[env_id]
+        self.num_envs = int(num_envs)
+        self.backend = backend
+        self.device_index = int(device)
+        self.observation_space, self.action_space = docking_spaces()
+        self._lib = _lib.load()
+        torch = _torch()
+        if not torch.cuda.is_available():
+            raise _lib.QuadsimError("VecDockingEnv needs a HIP device (torch.cuda.is_available() is False); "
+                                    "there is no CPU path")
+        self.device = torch.device("cuda", self.device_index)
+        cfg = _lib.default_config()
+        cfg.kind = self.kind
+        cfg.num_envs = self.num_envs
+        cfg.device = self.device_index
+        cfg.integrator = _INTEG[integrator]
+        cfg.dt = dt
+        cfg.auto_reset = 1 if auto_reset else 0
+        cfg.randomise = int(randomise)
+        cfg.io_space = _lib.IO_DEVICE
+        cfg.seed = int(seed)
+        cfg.env_id_offset = int(env_id_offset)
+        cfg.init_range = (C.c_float * 4)(*init_range)
+        cfg.mass_scale = (C.c_float * 2)(*mass_scale)
+        cfg.inertia_scale = (C.c_float * 2)(*inertia_scale)
+        cfg.mass = mass
+        cfg.inertia = (C.c_float * 3)(*inertia)
+        if use_torch_stream:
+            with torch.cuda.device(self.device):
+                cfg.stream = torch.cuda.current_stream().cuda_stream or None
+                cfg.external_stream = 1
+        self.cfg = cfg
+        self._h = C.c_void_p()
+        _lib.check(self._lib.qs_create(C.byref(cfg), C.byref(self._h)), "qs_create")
+        n = self.num_envs
+        kw = dict(device=self.device)
+        self._obs = torch.empty((n, 12), dtype=torch.float32, **kw)
+        self._rew = torch.empty((n,), dtype=torch.float32, **kw)
+        self._done = torch.empty((n,), dtype=torch.uint8, **kw)
+        self._flags = torch.empty((n,), dtype=torch.uint8, **kw)
+        self._term = torch.zeros((n, 12), dtype=torch.float32, **kw)
+        self._actions = None
+        self.auto_reset = bool(auto_reset)
+        # attribute surface the reference scripts poke (run_trained_docking_ppo2.py:45)
+        self.action_mean = np.ones(4) * mass * 9.81 / 2.0
+        self.action_std = np.ones(4) * mass * 9.81 / 2.0
+
+    # ------------------------------------------------------------------ plumbing
+    def _ptr(self, t):
+        return C.c_void_p(t.data_ptr()) if t is not None else None
+
+    def _as_device(self, x, shape, dtype=None):
+        torch = _torch()
+        dtype = dtype or torch.float32
+        if isinstance(x, torch.Tensor):
+            t = x.to(device=self.device, dtype=dtype)
+        else:
+            t = torch.as_tensor(np.ascontiguousarray(x), dtype=dtype).to(self.device)
+        t = t.contiguous()
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError("expected shape %s, got %s" % (tuple(shape), tuple(t.shape)))
+        return t
+
+    def _out(self, t):
+        return t.cpu().numpy() if self.backend == "numpy" else t
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            self._lib.qs_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        _lib.check(self._lib.qs_sync(self._h), "qs_sync")
+
+    # ------------------------------------------------------------------ VecEnv protocol
+    def reset(self, mask=None):
+        """DockingEnv.reset for all (or masked) envs -> obs [N,12]"""
+        m = None
+        if mask is not None:
+            m = self._as_device(mask, (self.num_envs,), _torch().uint8)
+        _lib.check(self._lib.qs_reset(self._h, self._ptr(m), self._ptr(self._obs)), "qs_reset")
+        return self._out(self._obs.clone() if self.backend == "torch" else self._obs)
+
+    def step_async(self, actions):
+        self._actions = self._as_device(actions, (self.num_envs, 4))
+        _lib.check(self._lib.qs_step(self._h, self._ptr(self._actions), self._ptr(self._obs), self._ptr(self._rew),
+                                     self._ptr(self._done), self._ptr(self._flags),
+                                     self._ptr(self._term) if self.auto_reset else None), "qs_step")
+
+    def step_wait(self):
+        if self.backend == "torch":
+            return self._obs, self._rew, self._done.bool(), InfoView(self)
+        obs, rew = self._obs.cpu().numpy(), self._rew.cpu().numpy()
+        done, flags = self._done.cpu().numpy().astype(bool), self._flags.cpu().numpy()
+        infos = InfoView(self, done=done, flags=flags)
+        return obs, rew, done, infos
+
+    def step(self, actions):
+        self.step_async(actions)
+        return self.step_wait()
+
+    def rollout(self, actions=None, T=None, want_flags=True):
+        """T fused steps in one launch (qs_rollout).  actions [T,N,4] or None (in-kernel U(-1,1)).
+        -> obs [T,N,12], reward [T,N], done [T,N] (uint8), flags [T,N] or None (torch tensors)."""
+        torch = _torch()
+        if actions is not None:
+            T = int(actions.shape[0])
+            actions = self._as_device(actions, (T, self.num_envs, 4))
+        elif T is None:
+            raise ValueError("give actions or T")
+        n = self.num_envs
+        obs = torch.empty((T, n, 12), dtype=torch.float32, device=self.device)
+        rew = torch.empty((T, n), dtype=torch.float32, device=self.device)
+        done = torch.empty((T, n), dtype=torch.uint8, device=self.device)
+        flags = torch.empty((T, n), dtype=torch.uint8, device=self.device) if want_flags else None
+        _lib.check(self._lib.qs_rollout(self._h, T, self._ptr(actions), self._ptr(obs), self._ptr(rew),
+                                        self._ptr(done), self._ptr(flags)), "qs_rollout")
+        return obs, rew, done, flags
+
+    def random_actions(self, T, step0=None):
+        """[T,N,4] synthetic U(-1,1) actions from the rocRAND action stream"""
+        torch = _torch()
+        if step0 is None:
+            step0 = self.step_counter
+        a = torch.empty((T, self.num_envs, 4), dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.qs_fill_random_actions(self._h, T, int(step0), self._ptr(a)), "qs_fill_random_actions")
+        return a
+
+    def seed(self, seed=None):
+        return [seed] * self.num_envs
+
+    def render(self, mode="human"):
+        return None
+
+    def get_attr(self, name, indices=None):
+        idx = range(self.num_envs) if indices is None else indices
+        if name in ("state_chaser", "state_target"):
+            st = self.get_state()
+            arr = st["chaser" if name == "state_chaser" else "target"]
+            return [arr[i] for i in idx]
+        return [getattr(self, name) for _ in idx]
+
+    def set_attr(self, name, value, indices=None):
+        setattr(self, name, value)
+
+    def env_method(self, method_name, *args, indices=None, **kwargs):
+        idx = range(self.num_envs) if indices is None else indices
+        return [getattr(self, method_name)(*args, **kwargs) for _ in idx]
+
+    # ------------------------------------------------------------------ state / params
+    @property
+    def step_counter(self):
+        k = C.c_uint64(0)
+        _lib.check(self._lib.qs_get_step_counter(self._h, C.byref(k)), "qs_get_step_counter")
+        return int(k.value)
+
+    @step_counter.setter
+    def step_counter(self, k):
+        _lib.check(self._lib.qs_set_step_counter(self._h, int(k)), "qs_set_step_counter")
+
+    def get_state(self, as_numpy=True):
+        """dict(chaser[N,13], target[N,13], u_prev[N,8], qdes[N,4], last_shaping[N], t[N])"""
+        torch = _torch()
+        n = self.num_envs
+        shapes = dict(chaser=(n, 13), target=(n, 13), u_prev=(n, 8), qdes=(n, 4), last_shaping=(n,), t=(n,))
+        bufs = {k: torch.empty(s, dtype=torch.float32, device=self.device) for k, s in shapes.items()}
+        _lib.check(self._lib.qs_get_state(self._h, *[self._ptr(bufs[k]) for k in shapes]), "qs_get_state")
+        return {k: (v.cpu().numpy() if as_numpy else v) for k, v in bufs.items()}
+
+    def set_state(self, chaser=None, target=None, u_prev=None, qdes=None, last_shaping=None, t=None):
+        n = self.num_envs
+        shapes = dict(chaser=(n, 13), target=(n, 13), u_prev=(n, 8), qdes=(n, 4), last_shaping=(n,), t=(n,))
+        given = dict(chaser=chaser, target=target, u_prev=u_prev, qdes=qdes, last_shaping=last_shaping, t=t)
+        ptrs, keep = [], []
+        for k, s in shapes.items():
+            if given[k] is None:
+                ptrs.append(None)
+            else:
+                tt = self._as_device(given[k], s)
+                keep.append(tt)
+                ptrs.append(self._ptr(tt))
+        _lib.check(self._lib.qs_set_state(self._h, *ptrs), "qs_set_state")
+        self.sync()
+
+    def set_params(self, mass=None, inertia=None):
+        n = self.num_envs
+        m = self._as_device(mass, (n,)) if mass is not None else None
+        i = self._as_device(inertia, (n, 3)) if inertia is not None else None
+        _lib.check(self._lib.qs_set_params(self._h, self._ptr(m), self._ptr(i)), "qs_set_params")
+        self.sync()
+
+    def get_params(self):
+        torch = _torch()
+        n = self.num_envs
+        m = torch.empty((n,), dtype=torch.float32, device=self.device)
+        i = torch.empty((n, 3), dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.qs_get_params(self._h, self._ptr(m), self._ptr(i)), "qs_get_params")
+        return m.cpu().numpy(), i.cpu().numpy()
+
+    def timer_start(self):
+        _lib.check(self._lib.qs_timer_start(self._h), "qs_timer_start")
+
+    def timer_stop(self):
+        ms = C.c_float(0)
+        _lib.check(self._lib.qs_timer_stop(self._h, C.byref(ms)), "qs_timer_stop")
+        return float(ms.value)
+
+
+class InfoView:
+    """infos[i] of the VecEnv protocol, materialised lazily: building N dicts per
+    step would dominate the step at N = 65 536.  infos[i] is a dict with the
+    reference's keys (docking_env.py:226-229) plus SB2's 'terminal_observation'."""
+
+    def __init__(self, env, done=None, flags=None):
+        self._env = env
+        self._done, self._flags = done, flags
+        self._term = None
+        self._state = None
+
+    def __len__(self):
+        return self._env.num_envs
+
+    def _materialise(self):
+        e = self._env
+        if self._done is None:
+            self._done = e._done.cpu().numpy().astype(bool)
+            self._flags = e._flags.cpu().numpy()
+        if self._term is None:
+            self._term = e._term.cpu().numpy()
+
+    def __getitem__(self, i):
+        self._materialise()
+        if self._state is None:
+            self._state = self._env.get_state()
+        f = int(self._flags[i])
+        info = {"chaser": self._state["chaser"][i], "target": self._state["target"][i],
+                "flag_docking": bool(f & _lib.FLAG_DOCKED), "done_overlimit": bool(f & _lib.FLAG_OVERLIMIT)}
+        if self._done[i] and self._env.auto_reset:
+            info["terminal_observation"] = self._term[i].copy()
+        return info
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+    @property
+    def flags(self):
+        self._materialise()
+        return self._flags
