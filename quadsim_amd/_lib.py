@@ -77,6 +77,10 @@ def load():
         raise QuadsimError(
             "%s is missing. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950). quadsim_amd has no CPU fallback." % LIB_PATH)
+    # torch (the owner of device memory and streams in this package) bundles its own HIP runtime;
+    # it must be the one already resident when libquadsim_hip.so resolves libamdhip64, otherwise two
+    # runtimes end up in one process and device pointers / streams cannot be shared.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     vp, i64, u64, i32, f32 = C.c_void_p, C.c_int64, C.c_uint64, C.c_int32, C.c_float
     sig = {

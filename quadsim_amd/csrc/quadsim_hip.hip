@@ -35,7 +35,7 @@ struct StepArgs {
     float *reward;         // [N] / [T,N]
     uint8_t *done;
     uint8_t *flags;        // nullable
-    float *term_obs;       // nullable, [N,12]
+    float *term_obs;       // nullable, [N,12] (T == 1 only)
     int64_t n;
     int64_t T;             // rollout length (1 for step)
     uint64_t step_idx;     // global step counter of the first step
@@ -125,9 +125,12 @@ __device__ __forceinline__ void step_and_maybe_reset(Env &e, Par &P, const float
     }
 }
 
-// K1: one fused env.step for N envs (DockingEnv.step, docking_env.py:104-231)
+// K1/K4: T fused env.steps for N envs in one launch, env state in registers between the tile load
+// and the tile store.  T == 1 is DockingEnv.step (docking_env.py:104-231); T > 1 is the trainer's
+// Runner loop (rl_baselines/ppo2/ppo2.py:472-499) with the actions pre-staged or drawn in-kernel.
+// One kernel serves both so that a roll-out is bit-identical to T single steps (same machine code).
 template <int INTEG, bool PARAMS>
-__global__ __launch_bounds__(kBlock) void k_step(StepArgs A)
+__global__ __launch_bounds__(kBlock) void k_env(StepArgs A)
 {
     const int lane = threadIdx.x & (kTile - 1);
     const int64_t tile = (int64_t)blockIdx.x * (kBlock / kTile) + (threadIdx.x >> 6);
@@ -137,37 +140,13 @@ __global__ __launch_bounds__(kBlock) void k_step(StepArgs A)
     load_env(A.st, tile, lane, e);
     Par P = A.par_nom;
     if (PARAMS) P = load_par(A.par, tile, lane);
-    const float4 av = reinterpret_cast<const float4 *>(A.actions)[env];
-    const float a[4] = {av.x, av.y, av.z, av.w};
-    float obs[12], reward;
-    unsigned flags;
-    bool done;
-    step_and_maybe_reset<INTEG, PARAMS>(e, P, a, A, env, A.step_idx, obs, reward, flags, done, true);
-    store_env(A.st, tile, lane, e);
-    if (PARAMS && A.randomise >= 2 && done && A.auto_reset) store_par(A.par, tile, lane, P);
-    store_obs(A.obs, env, obs);
-    A.reward[env] = reward;
-    A.done[env] = done ? 1 : 0;
-    if (A.flags) A.flags[env] = (uint8_t)flags;
-}
-
-// K4: T steps per launch, env state in registers (Runner loop, rl_baselines/ppo2/ppo2.py:472-499)
-template <int INTEG, bool PARAMS>
-__global__ __launch_bounds__(kBlock) void k_rollout(StepArgs A)
-{
-    const int lane = threadIdx.x & (kTile - 1);
-    const int64_t tile = (int64_t)blockIdx.x * (kBlock / kTile) + (threadIdx.x >> 6);
-    const int64_t env = tile * kTile + lane;
-    if (env >= A.n) return;
-    Env e;
-    load_env(A.st, tile, lane, e);
-    Par P = A.par_nom;
-    if (PARAMS) P = load_par(A.par, tile, lane);
+#pragma clang loop unroll(disable)
     for (int64_t t = 0; t < A.T; ++t) {
         const uint64_t k = A.step_idx + (uint64_t)t;
+        const int64_t o = t * A.n + env;
         float a[4];
         if (A.actions) {
-            const float4 av = reinterpret_cast<const float4 *>(A.actions)[t * A.n + env];
+            const float4 av = reinterpret_cast<const float4 *>(A.actions)[o];
             a[0] = av.x; a[1] = av.y; a[2] = av.z; a[3] = av.w;
         } else {
             random_action(A.rc.seed, A.gid0 + (uint64_t)env, k, a);
@@ -175,8 +154,7 @@ __global__ __launch_bounds__(kBlock) void k_rollout(StepArgs A)
         float obs[12], reward;
         unsigned flags;
         bool done;
-        step_and_maybe_reset<INTEG, PARAMS>(e, P, a, A, env, k, obs, reward, flags, done, false);
-        const int64_t o = t * A.n + env;
+        step_and_maybe_reset<INTEG, PARAMS>(e, P, a, A, env, k, obs, reward, flags, done, true);
         store_obs(A.obs, o, obs);
         A.reward[o] = reward;
         A.done[o] = done ? 1 : 0;
@@ -421,21 +399,11 @@ void launch_by_variant(K &&fn, int integ, bool params)
     else { if (params) fn.template operator()<1, true>(); else fn.template operator()<1, false>(); }
 }
 
-int launch_step(QsEnv *e, StepArgs &A)
+int launch_env(QsEnv *e, StepArgs &A)
 {
     const unsigned grid = grid_tiles(e->n);
     hipStream_t s = e->stream;
-    auto fn = [&]<int INTEG, bool PARAMS>() { hipLaunchKernelGGL((k_step<INTEG, PARAMS>), dim3(grid), dim3(kBlock), 0, s, A); };
-    launch_by_variant(fn, e->cfg.integrator, e->per_env_params);
-    HIP_TRY(hipGetLastError());
-    return QS_OK;
-}
-
-int launch_rollout(QsEnv *e, StepArgs &A)
-{
-    const unsigned grid = grid_tiles(e->n);
-    hipStream_t s = e->stream;
-    auto fn = [&]<int INTEG, bool PARAMS>() { hipLaunchKernelGGL((k_rollout<INTEG, PARAMS>), dim3(grid), dim3(kBlock), 0, s, A); };
+    auto fn = [&]<int INTEG, bool PARAMS>() { hipLaunchKernelGGL((k_env<INTEG, PARAMS>), dim3(grid), dim3(kBlock), 0, s, A); };
     launch_by_variant(fn, e->cfg.integrator, e->per_env_params);
     HIP_TRY(hipGetLastError());
     return QS_OK;
@@ -640,7 +608,7 @@ int qs_step(QsEnv *e, const float *actions, float *obs, float *reward, uint8_t *
     int r;
     if (e->cfg.io_space == QS_IO_DEVICE) {
         A.actions = actions; A.obs = obs; A.reward = reward; A.done = done; A.flags = flags; A.term_obs = terminal_obs;
-        r = launch_step(e, A);
+        r = launch_env(e, A);
         if (r) return r;
     } else {
         r = ensure_stage(e, (size_t)n * (4 * 4 + 12 * 4 + 4 + 1 + 1 + 12 * 4) + 4096);
@@ -653,7 +621,7 @@ int qs_step(QsEnv *e, const float *actions, float *obs, float *reward, uint8_t *
         if (terminal_obs) HIP_TRY(hipMemcpyAsync(d_term, terminal_obs, n * 12 * sizeof(float), hipMemcpyHostToDevice, e->stream));
         A.actions = d_act; A.obs = d_obs; A.reward = d_rew; A.done = d_done; A.flags = d_flags;
         A.term_obs = terminal_obs ? d_term : nullptr;
-        r = launch_step(e, A);
+        r = launch_env(e, A);
         if (r) return r;
         HIP_TRY(hipMemcpyAsync(obs, d_obs, n * 12 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipMemcpyAsync(reward, d_rew, n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
@@ -678,7 +646,7 @@ int qs_rollout(QsEnv *e, int64_t T, const float *actions, float *obs, float *rew
     int r;
     if (e->cfg.io_space == QS_IO_DEVICE) {
         A.actions = actions; A.obs = obs; A.reward = reward; A.done = done; A.flags = flags;
-        r = launch_rollout(e, A);
+        r = launch_env(e, A);
         if (r) return r;
     } else {
         r = ensure_stage(e, (size_t)tn * (4 * 4 + 12 * 4 + 4 + 1 + 1) + 4096);
@@ -688,7 +656,7 @@ int qs_rollout(QsEnv *e, int64_t T, const float *actions, float *obs, float *rew
         uint8_t *d_done = S.take<uint8_t>(tn), *d_flags = S.take<uint8_t>(tn);
         if (actions) HIP_TRY(hipMemcpyAsync(d_act, actions, tn * 4 * sizeof(float), hipMemcpyHostToDevice, e->stream));
         A.actions = actions ? d_act : nullptr; A.obs = d_obs; A.reward = d_rew; A.done = d_done; A.flags = d_flags;
-        r = launch_rollout(e, A);
+        r = launch_env(e, A);
         if (r) return r;
         HIP_TRY(hipMemcpyAsync(obs, d_obs, tn * 12 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipMemcpyAsync(reward, d_rew, tn * sizeof(float), hipMemcpyDeviceToHost, e->stream));

@@ -53,10 +53,15 @@ def test_g2_rel_obs_matches_reference_formula(qa, oracle64):
     sc32, st32 = sc.astype(np.float32), st.astype(np.float32)
     obs = qa.rel_obs_batch(sc32, st32)
     ref = np.array([oracle64.rel_obs(sc32[i].astype(np.float64), st32[i].astype(np.float64)) for i in range(n)])
-    # exclude gimbal-lock rows (|phi| within 1e-3 of pi/2: tan/sec amplify any rounding without bound)
-    ok = np.abs(np.abs(ref[:, 6]) - np.pi / 2) > 1e-2
-    assert ok.sum() > 150
-    np.testing.assert_allclose(obs[ok, :9], ref[ok, :9], rtol=1e-5, atol=2e-5)
+    # The reference's "rotation" has unit diagonal, so R_A2B[1,2] saturates (phi = +-pi/2, theta = 0)
+    # for many quaternion pairs: those rows pin the saturation branches.  Rows NEAR the branch point
+    # are excluded (tan/sec amplify any rounding without bound there; knife-edge for the branch).
+    sat = np.abs(ref[:, 6]) == np.pi / 2
+    near = ~sat & (np.abs(np.abs(ref[:, 6]) - np.pi / 2) < 1e-2)
+    ok = ~sat & ~near
+    assert sat.sum() > 30 and ok.sum() > 60
+    np.testing.assert_allclose(obs[~near, :9], ref[~near, :9], rtol=1e-5, atol=2e-5)
+    assert np.all(obs[sat, 7] == 0.0)
     scale = 1.0 + np.abs(np.tan(ref[ok, 6]))[:, None] * 5
     assert np.all(np.abs(obs[ok, 9:] - ref[ok, 9:]) <= 2e-5 * scale * (1 + np.abs(ref[ok, 9:])))
 
