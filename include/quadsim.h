@@ -131,6 +131,12 @@ int qs_step(QsEnv *env, const float *actions, float *obs, float *reward, uint8_t
 int qs_rollout(QsEnv *env, int64_t T, const float *actions, float *obs, float *reward, uint8_t *done,
                uint8_t *flags);
 
+/* Same contract and bit-identical results as qs_rollout, but issued as T single-step launches from
+ * native code (what a per-step trainer loop costs the GPU, without the interpreter between launches).
+ * actions [T,N,4] required. */
+int qs_rollout_stepwise(QsEnv *env, int64_t T, const float *actions, float *obs, float *reward, uint8_t *done,
+                        uint8_t *flags);
+
 /* U(-1,1) synthetic actions [T,N,4] for steps step0 .. step0+T-1 (rocRAND Philox4x32-10 action stream;
  * identical to what qs_rollout draws in-kernel when actions == NULL). */
 int qs_fill_random_actions(QsEnv *env, int64_t T, uint64_t step0, float *actions);

@@ -10,7 +10,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-LIB_PATH = os.path.join(CSRC, "libquadsim_hip.so")
+LIB_PATH = os.environ.get("QUADSIM_HIP_LIB") or os.path.join(CSRC, "libquadsim_hip.so")  # override: A/B builds
 SOURCES = [os.path.join(CSRC, "quadsim_hip.hip")]
 HEADERS = [os.path.join(CSRC, "quadsim_device.hpp"), os.path.join(HERE, "..", "include", "quadsim.h")]
 
@@ -23,7 +23,7 @@ FLAG_DOCKED, FLAG_OVERLIMIT, FLAG_OVERTIME, FLAG_CHASER_LIMITED, FLAG_TARGET_LIM
 
 EXPORTS = [
     "qs_config_default", "qs_version", "qs_last_error", "qs_create", "qs_destroy", "qs_reset", "qs_step",
-    "qs_rollout", "qs_fill_random_actions", "qs_get_state", "qs_set_state", "qs_set_params", "qs_get_params",
+    "qs_rollout", "qs_rollout_stepwise", "qs_fill_random_actions", "qs_get_state", "qs_set_state", "qs_set_params", "qs_get_params",
     "qs_get_step_counter", "qs_set_step_counter", "qs_set_stream", "qs_sync", "qs_timer_start", "qs_timer_stop",
     "qs_drone_step", "qs_ctrl", "qs_rel_obs",
 ]
@@ -57,7 +57,9 @@ def build_library(force=False, verbose=False):
     if (not force and os.path.exists(LIB_PATH)
             and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps)):
         return LIB_PATH
-    cmd = [hipcc_path(), "-std=c++20", "-O3", "--offload-arch=gfx950", "-fPIC", "-shared",
+    # -fno-slp-vectorize: SLP packs the scalar f32 chains into v_pk_* pairs at the price of ~300 extra
+    # v_mov and +56 VGPRs; measured 5 % slower on the step kernel (profiles/r01/ab_slp.txt)
+    cmd = [hipcc_path(), "-std=c++20", "-O3", "-fno-slp-vectorize", "--offload-arch=gfx950", "-fPIC", "-shared",
            "-Wno-unused-result", *SOURCES, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
@@ -91,6 +93,7 @@ def load():
         "qs_reset": [vp, vp, vp],
         "qs_step": [vp, vp, vp, vp, vp, vp, vp],
         "qs_rollout": [vp, i64, vp, vp, vp, vp, vp],
+        "qs_rollout_stepwise": [vp, i64, vp, vp, vp, vp, vp],
         "qs_fill_random_actions": [vp, i64, u64, vp],
         "qs_get_state": [vp] + [vp] * 6,
         "qs_set_state": [vp] + [vp] * 6,

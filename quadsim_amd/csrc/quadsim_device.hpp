@@ -50,15 +50,74 @@ struct EnvConst {
 };
 
 // ---------------------------------------------------------------------------
-// scalar math.  1-ulp hardware reciprocal / rsqrt / sqrt; ocml for the inverse
-// trig (accurate to ~1 ulp, arguments are bounded so no slow paths are taken).
+// scalar math.  Hardware rcp / rsq / sqrt (1 ulp) and hand-rolled inverse trig /
+// sincos: the arguments on this path are bounded (angles in [-pi, pi], ratios in
+// [0, 1]), so none of libm's huge-argument or denormal paths are needed.
+// Polynomials are near-minimax fits (tools/fit_polys.py); measured against
+// float64 on the full argument range: atan2 <= 1.1e-7 abs, asin <= 9.3e-8 abs,
+// sin <= 4.4e-8, cos <= 7.4e-8 abs -- about 1 ulp of the result's scale.
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ float q_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 __device__ __forceinline__ float q_rsqrt(float x) { return __builtin_amdgcn_rsqf(x); }
 __device__ __forceinline__ float q_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
-__device__ __forceinline__ float q_asin(float x) { return asinf(x); }
-__device__ __forceinline__ float q_atan2(float y, float x) { return atan2f(y, x); }
-__device__ __forceinline__ void q_sincos(float x, float &s, float &c) { sincosf(x, &s, &c); }
+
+// asin on [-1, 1]: x + x z P(z) for |x| <= 1/2, pi/2 - 2 asin(sqrt((1-|x|)/2)) above
+__device__ __forceinline__ float q_asin(float x)
+{
+    float a = fabsf(x);
+    bool big = a > 0.5f;
+    float z = big ? fmaf(-0.5f, a, 0.5f) : a * a;
+    float s = big ? q_sqrt(z) : a;
+    float p = 0.038206227123737335f;
+    p = fmaf(p, z, 0.026494402438402176f);
+    p = fmaf(p, z, 0.04501067474484444f);
+    p = fmaf(p, z, 0.07498809695243835f);
+    p = fmaf(p, z, 0.16666673123836517f);
+    float r = fmaf(s * z, p, s);
+    r = big ? fmaf(-2.0f, r, kHalfPi) : r;
+    return copysignf(r, x);
+}
+
+// atan2 for finite arguments; atan2(0, 0) = 0 like numpy.  atan(t) = t + t s P(s), s = t^2, t in [0, 1].
+__device__ __forceinline__ float q_atan2(float y, float x)
+{
+    float ax = fabsf(x), ay = fabsf(y);
+    float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float t = mn * q_rcp(mx);
+    t = (mx == 0.0f) ? 0.0f : t;
+    float s = t * t;
+    float p = 0.0028340641874819994f;
+    p = fmaf(p, s, -0.016005029901862144f);
+    p = fmaf(p, s, 0.042587608098983765f);
+    p = fmaf(p, s, -0.07495445758104324f);
+    p = fmaf(p, s, 0.10636754333972931f);
+    p = fmaf(p, s, -0.14202570915222168f);
+    p = fmaf(p, s, 0.19992484152317047f);
+    p = fmaf(p, s, -0.3333306610584259f);
+    float r = fmaf(t * s, p, t);
+    r = (ay > ax) ? (kHalfPi - r) : r;
+    r = (x < 0.0f) ? (kPi - r) : r;
+    return copysignf(r, y);
+}
+
+// sin and cos for |x| <~ 1e4: two-constant Cody-Waite reduction by pi/2 (exact with fma),
+// degree-7 / degree-8 polynomials on [-pi/4, pi/4], quadrant fix-up by sign-bit arithmetic.
+__device__ __forceinline__ void q_sincos(float x, float &sn, float &cs)
+{
+    float kf = rintf(x * 0.636619772367581343f);
+    float r = fmaf(kf, -1.57079637050628662109375f, x);
+    r = fmaf(kf, 4.37113900018624283e-8f, r);
+    int k = (int)kf;
+    float z = r * r;
+    float sp = fmaf(fmaf(-0.0001958291686605662f, z, 0.008332724682986736f), z, -0.166666641831398f);
+    float s0 = fmaf(r * z, sp, r);
+    float cp = fmaf(fmaf(2.4542947357986122e-05f, z, -0.0013888279208913445f), z, 0.0416666641831398f);
+    float c0 = fmaf(z * z, cp, fmaf(-0.5f, z, 1.0f));
+    bool swap = (k & 1) != 0;
+    float ss = swap ? c0 : s0, cc = swap ? s0 : c0;
+    sn = __uint_as_float(__float_as_uint(ss) ^ (((unsigned)k & 2u) << 30));
+    cs = __uint_as_float(__float_as_uint(cc) ^ (((unsigned)(k + 1) & 2u) << 30));
+}
 
 // off-diagonal entries of the reference's quat2rot (diagonal is identically 1):
 // utils/transform.py:4-20 == dynamics/quadrotor.py:226-245.  Element-wise
@@ -99,13 +158,34 @@ __device__ __forceinline__ void quat2euler(const float q[4], float &phi, float &
     theta = (r12 >= 1.0f || r12 < -1.0f) ? 0.0f : th;
 }
 
-// yaw only (what hover/vel_controller read back from state_des, PIDController.py:87-88)
-__device__ __forceinline__ float quat2yaw(const float q[4])
+// sin/cos of the yaw psi = atan2(-r10, r11) of quat2euler and of psi/2, by algebra instead of
+// atan2 + sincos: (cos psi, sin psi) = (r11, -r10)/hypot, half angles from the branch that
+// does not cancel.  (What hover/vel_controller read back from state_des, PIDController.py:87-91,100.)
+__device__ __forceinline__ void quat_yaw_trig(const float q[4], float &sp, float &cp, float &sh, float &ch)
 {
     float w = q[0], x = q[1], y = q[2], z = q[3];
     float r10 = 2.0f * (x * y - w * z);
     float r11 = w * w - x * x + y * y - z * z;
-    return q_atan2(-r10, r11);
+    float h2 = r10 * r10 + r11 * r11;
+    float ih = q_rsqrt(h2);
+    bool degenerate = !(h2 > 0.0f);                       // atan2(0,0) = 0
+    sp = degenerate ? 0.0f : -r10 * ih;
+    cp = degenerate ? 1.0f : r11 * ih;
+    // half angle from the branch that does not cancel: cos(psi/2) when cos psi >= 0, |sin(psi/2)| otherwise
+    bool pos = cp >= 0.0f;
+    float big = q_sqrt(fmaf(pos ? 0.5f : -0.5f, cp, 0.5f));
+    float small = 0.5f * fabsf(sp) * q_rcp(big);
+    ch = pos ? big : small;
+    sh = copysignf(pos ? small : big, sp);
+}
+
+// euler2quat from precomputed half-angle sines / cosines (utils/transform.py:123-136)
+__device__ __forceinline__ void euler2quat_trig(float sr, float cr, float sp, float cp, float sy, float cy, float q[4])
+{
+    q[0] = cr * cp * cy - sr * sp * sy;
+    q[1] = sr * cp * cy - cr * sp * sy;
+    q[2] = sr * cp * sy + cr * sp * cy;
+    q[3] = cr * cp * sy + sr * sp * cy;
 }
 
 // utils/transform.py:123-136
@@ -152,22 +232,35 @@ __device__ __forceinline__ void drone_df(const float s[13], const float u[4], co
 }
 
 // Drone.attitude_limit + write-back, dynamics/quadrotor.py:146-168,:135-138.
-// Sequential overriding ifs == the LAST violated axis wins, each built from the
-// un-clamped other two angles; the final `<=` test cancels an exact tie.
+// The three threshold tests are made on the matrix entries instead of the angles
+// (asin and atan2 are monotone): |roll| >= 85deg <=> |clamp r12| >= sin 85deg;
+// |pitch| >= 85deg <=> r22 <= |r02| cot 85deg (pitch is 0 on the saturated branches);
+// |yaw| >= 175deg <=> r11 < 0 and |r10| <= -r11 tan 5deg.  The angles themselves are only
+// evaluated in the rare branch where a limit fires.  Sequential overriding ifs of the
+// reference == the LAST violated axis wins, built from the un-clamped other two angles.
 __device__ __forceinline__ bool attitude_limit(float s[13])
 {
-    float r, p, y;
-    quat2euler(s + 6, r, p, y);
-    float ar = fabsf(r), ap = fabsf(p), ay = fabsf(y);
-    bool a = ar >= kLim85, b = ap >= kLim85, c = ay >= kLim175;
-    bool inside = (ar <= kLim85) && (ap <= kLim85) && (ay <= kLim175);
-    bool over = (a || b || c) && !inside;
+    constexpr float kSin85 = 0.99619469809174555f;
+    constexpr float kTan5 = 0.087488663525924005f;
+    float w = s[6], x = s[7], y = s[8], z = s[9];
+    float r10 = 2.0f * (x * y - w * z);
+    float r11 = w * w - x * x + y * y - z * z;
+    float r12 = 2.0f * (w * x + y * z);
+    float r02 = 2.0f * (x * z - w * y);
+    float r22 = w * w - x * x - y * y + z * z;
+    bool sat = (r12 >= 1.0f) || (r12 < -1.0f);
+    bool a = fabsf(r12) >= kSin85;
+    bool b = !sat && (r22 <= fabsf(r02) * kTan5) && !(r02 == 0.0f && r22 == 0.0f);
+    bool c = (r11 < 0.0f) && (fabsf(r10) <= -r11 * kTan5);
+    bool over = a || b || c;
     if (over) {
-        float er = r, ep = p, ey = y;
-        if (c) ey = copysignf(kLim175, y);
-        else if (b) ep = copysignf(kLim85, p);
-        else er = copysignf(kLim85, r);
-        euler2quat(er, ep, ey, s + 6);
+        float r = q_asin(fminf(fmaxf(r12, -1.0f), 1.0f));
+        float p = sat ? 0.0f : q_atan2(-r02, r22);
+        float yw = q_atan2(-r10, r11);
+        if (c) yw = copysignf(kLim175, yw);
+        else if (b) p = copysignf(kLim85, p);
+        else r = copysignf(kLim85, r);
+        euler2quat(r, p, yw, s + 6);
         s[10] = 0.0f; s[11] = 0.0f; s[12] = 0.0f;
     }
     return over;
@@ -237,13 +330,15 @@ __device__ __forceinline__ void attitude_controller(const float qdes[4], float w
 __device__ __forceinline__ float desired_attitude(float ax, float ay, float az, float qdes[4], float m)
 {
     float F = fmaf(m, az, m * kG);
-    float psi = quat2yaw(qdes);
-    float sp, cp;
-    q_sincos(psi, sp, cp);
+    float sp, cp, sh, ch;
+    quat_yaw_trig(qdes, sp, cp, sh, ch);
     constexpr float inv_g = 1.0f / kG;
     float phi_des = (ax * sp - ay * cp) * inv_g;
     float theta_des = (ax * cp + ay * sp) * inv_g;
-    euler2quat(phi_des, theta_des, psi, qdes);
+    float sr, cr, st, ct;
+    q_sincos(0.5f * phi_des, sr, cr);
+    q_sincos(0.5f * theta_des, st, ct);
+    euler2quat_trig(sr, cr, st, ct, sh, ch, qdes);
     return F;
 }
 
@@ -310,9 +405,15 @@ __device__ __forceinline__ void rel_obs(const float sc[13], const float st[13], 
     float P = (wt0 + B.r01 * wt1 + B.r02 * wt2) - (R00 * a0 + R01 * a1 + R02 * a2);
     float Q = (B.r10 * wt0 + wt1 + B.r12 * wt2) - (R10 * a0 + R11 * a1 + R12 * a2);
     float Rr = (B.r20 * wt0 + B.r21 * wt1 + wt2) - (R20 * a0 + R21 * a1 + R22 * a2);
-    float sth, cth, sph, cph;
-    q_sincos(theta, sth, cth);
-    q_sincos(phi, sph, cph);
+    // sin/cos of theta = atan2(-R02, R22) and of phi = asin(R12) by algebra (no sincos)
+    bool satur = (R12 >= 1.0f || R12 < -1.0f);
+    float h2 = R02 * R02 + R22 * R22;
+    float ih = q_rsqrt(h2);
+    bool flat = satur || !(h2 > 0.0f);
+    float sth = flat ? 0.0f : -R02 * ih;
+    float cth = flat ? 1.0f : R22 * ih;
+    float sph = fminf(fmaxf(R12, -1.0f), 1.0f);
+    float cph = q_sqrt((1.0f - sph) * (1.0f + sph));
     float k = Rr * cth - P * sth;
     float icph = q_rcp(cph);
     o[6] = phi; o[7] = theta; o[8] = psi;
@@ -350,13 +451,15 @@ __device__ __forceinline__ uint4 philox_block(uint64_t seed, uint64_t stream, ui
 
 // randomised initial state (+ per-episode params): 16 uniforms = blocks 4*ctr..4*ctr+3.
 // Build extension; the reference's v0/v2 have no randomness.
+template <bool WITH_PAR>
 __device__ __forceinline__ void random_init(const RandCfg &rc, uint64_t stream, uint64_t gid, uint64_t ctr,
                                             float sc[13], float st[13], Par &P)
 {
     uint4 w0 = philox_block(rc.seed, stream, gid, 4ull * ctr + 0);
     uint4 w1 = philox_block(rc.seed, stream, gid, 4ull * ctr + 1);
     uint4 w2 = philox_block(rc.seed, stream, gid, 4ull * ctr + 2);
-    uint4 w3 = philox_block(rc.seed, stream, gid, 4ull * ctr + 3);
+    uint4 w3 = make_uint4(0u, 0u, 0u, 0u);
+    if (WITH_PAR) w3 = philox_block(rc.seed, stream, gid, 4ull * ctr + 3);
     nominal_init(sc, st);
     sc[0] = __fmaf_rn(sym(u01(w0.x)), rc.rr[0], 8.0f);
     sc[1] = __fmaf_rn(sym(u01(w0.y)), rc.rr[0], -50.0f);

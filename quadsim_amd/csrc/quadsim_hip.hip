@@ -45,6 +45,7 @@ struct StepArgs {
     Par par_nom;
     int auto_reset;
     int randomise;
+    float nominal_obs[12]; // state2rel of the nominal reset states (what a non-randomised reset returns)
 };
 
 __device__ __forceinline__ void load_env(const float *__restrict__ st, int64_t tile, int lane, Env &e)
@@ -104,7 +105,8 @@ __device__ __forceinline__ void store_obs(float *__restrict__ obs, int64_t env, 
 }
 
 // one env.step for the lane's env + VecEnv auto-reset; shared by step and rollout kernels
-template <int INTEG, bool PARAMS>
+// RMODE (compile time) = the handle's `randomise`: 0 nominal reset, 1 rocRAND init state, 2 + params.
+template <int INTEG, bool PARAMS, int RMODE>
 __device__ __forceinline__ void step_and_maybe_reset(Env &e, Par &P, const float a[4], const StepArgs &A, int64_t env,
                                                      uint64_t k, float obs[12], float &reward, unsigned &flags,
                                                      bool &done, bool write_term)
@@ -113,15 +115,22 @@ __device__ __forceinline__ void step_and_maybe_reset(Env &e, Par &P, const float
     done = (flags & (FLAG_OVERLIMIT | FLAG_OVERTIME)) != 0;
     if (done && A.auto_reset) {
         if (write_term && A.term_obs) store_obs(A.term_obs, env, obs);
-        float ic[13], it[13];
-        if (A.randomise) {
-            Par Pn;
-            random_init(A.rc, STREAM_AUTORESET, A.gid0 + (uint64_t)env, k + 1, ic, it, Pn);
-            if (PARAMS && A.randomise >= 2) P = Pn;
+        if (RMODE == 0) {
+            // nominal states are constants: no need to re-derive their observation per lane
+            nominal_init(e.sc, e.st);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { e.uc[i] = 0.0f; e.ut[i] = 0.0f; }
+            e.ls = 0.0f;
+            e.t = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 12; ++i) obs[i] = A.nominal_obs[i];
         } else {
-            nominal_init(ic, it);
+            float ic[13], it[13];
+            Par Pn;
+            random_init<RMODE >= 2>(A.rc, STREAM_AUTORESET, A.gid0 + (uint64_t)env, k + 1, ic, it, Pn);
+            if (PARAMS && RMODE >= 2) P = Pn;
+            env_reset(e, ic, it, obs);
         }
-        env_reset(e, ic, it, obs);
     }
 }
 
@@ -129,7 +138,7 @@ __device__ __forceinline__ void step_and_maybe_reset(Env &e, Par &P, const float
 // and the tile store.  T == 1 is DockingEnv.step (docking_env.py:104-231); T > 1 is the trainer's
 // Runner loop (rl_baselines/ppo2/ppo2.py:472-499) with the actions pre-staged or drawn in-kernel.
 // One kernel serves both so that a roll-out is bit-identical to T single steps (same machine code).
-template <int INTEG, bool PARAMS>
+template <int INTEG, bool PARAMS, int RMODE>
 __global__ __launch_bounds__(kBlock) void k_env(StepArgs A)
 {
     const int lane = threadIdx.x & (kTile - 1);
@@ -154,14 +163,14 @@ __global__ __launch_bounds__(kBlock) void k_env(StepArgs A)
         float obs[12], reward;
         unsigned flags;
         bool done;
-        step_and_maybe_reset<INTEG, PARAMS>(e, P, a, A, env, k, obs, reward, flags, done, true);
+        step_and_maybe_reset<INTEG, PARAMS, RMODE>(e, P, a, A, env, k, obs, reward, flags, done, true);
         store_obs(A.obs, o, obs);
         A.reward[o] = reward;
         A.done[o] = done ? 1 : 0;
         if (A.flags) A.flags[o] = (uint8_t)flags;
     }
     store_env(A.st, tile, lane, e);
-    if (PARAMS && A.randomise >= 2) store_par(A.par, tile, lane, P);
+    if (PARAMS && RMODE >= 2) store_par(A.par, tile, lane, P);
 }
 
 // K2: masked reset (DockingEnv.reset, docking_env.py:233-244); init_all also rewrites q_des, like __init__
@@ -177,7 +186,7 @@ __global__ __launch_bounds__(kBlock) void k_reset(StepArgs A, const uint8_t *__r
     float ic[13], it[13], obs[12];
     if (A.randomise) {
         Par Pn;
-        random_init(A.rc, STREAM_RESET, A.gid0 + (uint64_t)env, A.step_idx, ic, it, Pn);
+        random_init<true>(A.rc, STREAM_RESET, A.gid0 + (uint64_t)env, A.step_idx, ic, it, Pn);
         if (A.randomise >= 2) store_par(A.par, tile, lane, Pn);
     } else {
         nominal_init(ic, it);
@@ -186,6 +195,14 @@ __global__ __launch_bounds__(kBlock) void k_reset(StepArgs A, const uint8_t *__r
     env_reset(e, ic, it, obs);
     store_env(A.st, tile, lane, e);
     if (A.obs) store_obs(A.obs, env, obs);
+}
+
+__global__ void k_nominal_obs(float *out)
+{
+    float sc[13], st[13], o[12];
+    nominal_init(sc, st);
+    rel_obs(sc, st, o);
+    for (int i = 0; i < 12; ++i) out[i] = o[i];
 }
 
 __global__ __launch_bounds__(kBlock) void k_fill_par(float *par, int64_t n, Par P)
@@ -338,6 +355,7 @@ struct QsEnv {
     bool own_stream = false;
     uint64_t step = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    float nominal_obs[12] = {0};
     // staging for QS_IO_HOST
     void *stage = nullptr;
     size_t stage_bytes = 0;
@@ -368,6 +386,7 @@ StepArgs make_args(const QsEnv *e)
     A.par_nom = Par{e->cfg.mass, e->cfg.inertia[0], e->cfg.inertia[1], e->cfg.inertia[2]};
     A.auto_reset = e->cfg.auto_reset;
     A.randomise = e->cfg.randomise;
+    for (int i = 0; i < 12; ++i) A.nominal_obs[i] = e->nominal_obs[i];
     return A;
 }
 
@@ -392,19 +411,25 @@ struct Stage {
     }
 };
 
-template <typename K>
-void launch_by_variant(K &&fn, int integ, bool params)
+template <int INTEG, bool PARAMS, int RMODE>
+void launch_one(unsigned grid, hipStream_t s, const StepArgs &A)
 {
-    if (integ == QS_INTEG_FROZEN) { if (params) fn.template operator()<0, true>(); else fn.template operator()<0, false>(); }
-    else { if (params) fn.template operator()<1, true>(); else fn.template operator()<1, false>(); }
+    hipLaunchKernelGGL((k_env<INTEG, PARAMS, RMODE>), dim3(grid), dim3(kBlock), 0, s, A);
+}
+
+template <int INTEG>
+void launch_integ(unsigned grid, hipStream_t s, const StepArgs &A, bool params, int rmode)
+{
+    if (rmode >= 2) launch_one<INTEG, true, 2>(grid, s, A);      // per-episode params imply per-env params
+    else if (rmode == 1) { if (params) launch_one<INTEG, true, 1>(grid, s, A); else launch_one<INTEG, false, 1>(grid, s, A); }
+    else { if (params) launch_one<INTEG, true, 0>(grid, s, A); else launch_one<INTEG, false, 0>(grid, s, A); }
 }
 
 int launch_env(QsEnv *e, StepArgs &A)
 {
     const unsigned grid = grid_tiles(e->n);
-    hipStream_t s = e->stream;
-    auto fn = [&]<int INTEG, bool PARAMS>() { hipLaunchKernelGGL((k_env<INTEG, PARAMS>), dim3(grid), dim3(kBlock), 0, s, A); };
-    launch_by_variant(fn, e->cfg.integrator, e->per_env_params);
+    if (e->cfg.integrator == QS_INTEG_FROZEN) launch_integ<0>(grid, e->stream, A, e->per_env_params, e->cfg.randomise);
+    else launch_integ<1>(grid, e->stream, A, e->per_env_params, e->cfg.randomise);
     HIP_TRY(hipGetLastError());
     return QS_OK;
 }
@@ -496,13 +521,19 @@ int qs_create(const QsConfig *cfg, QsEnv **out)
         HIP_TRY(hipEventCreate(&e->ev0));
         HIP_TRY(hipEventCreate(&e->ev1));
         const size_t st_bytes = (size_t)e->tiles * kRecWords * kTile * sizeof(float);
-        const size_t par_bytes = (size_t)e->tiles * kParWords * kTile * sizeof(float);
+        const size_t par_bytes = (size_t)e->tiles * kParWords * kTile * sizeof(float) + 64;  // + scratch for nominal_obs
         HIP_TRY(hipMalloc((void **)&e->st, st_bytes));
         HIP_TRY(hipMalloc((void **)&e->par, par_bytes));
         HIP_TRY(hipMemsetAsync(e->st, 0, st_bytes, e->stream));
         HIP_TRY(hipMemsetAsync(e->par, 0, par_bytes, e->stream));
         int r = fill_params(e);
         if (r) return r;
+        // observation of the nominal reset, evaluated once by the same device code the kernels use
+        hipLaunchKernelGGL(k_nominal_obs, dim3(1), dim3(1), 0, e->stream, e->par + (size_t)e->tiles * kParWords * kTile);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(e->nominal_obs, e->par + (size_t)e->tiles * kParWords * kTile, 12 * sizeof(float),
+                               hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
         // __init__: nominal states, q_des = identity; never randomised (randomisation starts at the first reset)
         StepArgs A = make_args(e);
         A.randomise = 0;
@@ -663,6 +694,28 @@ int qs_rollout(QsEnv *e, int64_t T, const float *actions, float *obs, float *rew
         HIP_TRY(hipMemcpyAsync(done, d_done, tn, hipMemcpyDeviceToHost, e->stream));
         if (flags) HIP_TRY(hipMemcpyAsync(flags, d_flags, tn, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    e->step += (uint64_t)T;
+    return QS_OK;
+}
+
+int qs_rollout_stepwise(QsEnv *e, int64_t T, const float *actions, float *obs, float *reward, uint8_t *done, uint8_t *flags)
+{
+    CHECK_ENV(e);
+    if (T < 1 || !actions || !obs || !reward || !done) return fail(QS_ERR_INVALID, "qs_rollout_stepwise: bad arguments");
+    if (!e->cfg.auto_reset) return fail(QS_ERR_INVALID, "qs_rollout_stepwise: requires auto_reset");
+    if (e->cfg.io_space != QS_IO_DEVICE) return fail(QS_ERR_INVALID, "qs_rollout_stepwise: device buffers only");
+    const int64_t n = e->n;
+    StepArgs A = make_args(e);
+    for (int64_t t = 0; t < T; ++t) {
+        A.step_idx = e->step + (uint64_t)t;
+        A.actions = actions + t * n * 4;
+        A.obs = obs + t * n * 12;
+        A.reward = reward + t * n;
+        A.done = done + t * n;
+        A.flags = flags ? flags + t * n : nullptr;
+        int r = launch_env(e, A);
+        if (r) return r;
     }
     e->step += (uint64_t)T;
     return QS_OK;

@@ -164,8 +164,10 @@ class VecDockingEnv:
         self.step_async(actions)
         return self.step_wait()
 
-    def rollout(self, actions=None, T=None, want_flags=True):
-        """T fused steps in one launch (qs_rollout).  actions [T,N,4] or None (in-kernel U(-1,1)).
+    def rollout(self, actions=None, T=None, want_flags=True, stepwise=False, out=None):
+        """T fused steps in one launch (qs_rollout), or T single-step launches issued from native code
+        (stepwise=True, qs_rollout_stepwise).  actions [T,N,4] or None (in-kernel U(-1,1), fused only).
+        out: optional (obs, reward, done, flags) tensors to write into.
         -> obs [T,N,12], reward [T,N], done [T,N] (uint8), flags [T,N] or None (torch tensors)."""
         torch = _torch()
         if actions is not None:
@@ -174,12 +176,16 @@ class VecDockingEnv:
         elif T is None:
             raise ValueError("give actions or T")
         n = self.num_envs
-        obs = torch.empty((T, n, 12), dtype=torch.float32, device=self.device)
-        rew = torch.empty((T, n), dtype=torch.float32, device=self.device)
-        done = torch.empty((T, n), dtype=torch.uint8, device=self.device)
-        flags = torch.empty((T, n), dtype=torch.uint8, device=self.device) if want_flags else None
-        _lib.check(self._lib.qs_rollout(self._h, T, self._ptr(actions), self._ptr(obs), self._ptr(rew),
-                                        self._ptr(done), self._ptr(flags)), "qs_rollout")
+        if out is not None:
+            obs, rew, done, flags = out
+        else:
+            obs = torch.empty((T, n, 12), dtype=torch.float32, device=self.device)
+            rew = torch.empty((T, n), dtype=torch.float32, device=self.device)
+            done = torch.empty((T, n), dtype=torch.uint8, device=self.device)
+            flags = torch.empty((T, n), dtype=torch.uint8, device=self.device) if want_flags else None
+        fn = self._lib.qs_rollout_stepwise if stepwise else self._lib.qs_rollout
+        _lib.check(fn(self._h, T, self._ptr(actions), self._ptr(obs), self._ptr(rew), self._ptr(done),
+                      self._ptr(flags)), "qs_rollout")
         return obs, rew, done, flags
 
     def random_actions(self, T, step0=None):
