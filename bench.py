@@ -185,6 +185,16 @@ def main():
                               % (n * 160 / 1e6)},
     }
 
+    # HBM-side bytes per launch from the PMC passes (collected separately: rocprofv3 --pmc cannot run inside
+    # this process); only quoted when the profile was taken on this very configuration
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
+        if pmc["envs"] == n and args.env == "docking-v0" and args.integrator == "frozen" and args.randomise == 1:
+            out["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
+            out["roofline"]["traffic_source"] = pmc["source"]
+    except (OSError, ValueError, KeyError):
+        pass
+
     if not args.no_extras:
         # fused roll-out leg: T steps per launch, state in registers (different algorithmic bytes: see DESIGN.md)
         T = args.rollout_T
@@ -216,16 +226,14 @@ def main():
         env_o.close()
         if distributed:
             # BASELINE configs 4/5: RCCL all-gather of the roll-out slabs (obs, reward, done) once per T-step roll-out
-            obs_all = torch.empty((world,) + (T, n, 12), dtype=torch.float32, device="cuda")
-            rew_all = torch.empty((world,) + (T, n), dtype=torch.float32, device="cuda")
-            done_all = torch.empty((world,) + (T, n), dtype=torch.uint8, device="cuda")
+            from quadsim_amd.distributed import gather_rollout
+            o_, r_, d_, _f = env.rollout(acts, want_flags=False)
+            gathered = gather_rollout(o_, r_, d_)
             barrier()
             t0 = time.perf_counter()
             for _ in range(reps):
                 o_, r_, d_, _f = env.rollout(acts, want_flags=False)
-                dist.all_gather_into_tensor(obs_all, o_)
-                dist.all_gather_into_tensor(rew_all, r_)
-                dist.all_gather_into_tensor(done_all, d_)
+                gather_rollout(o_, r_, d_, out=gathered)
             torch.cuda.synchronize()
             w4 = max_over_ranks(time.perf_counter() - t0)
             out["allgather"] = {"value": total_envs * T * reps / w4, "unit": "env-steps/s",

@@ -362,3 +362,44 @@ def test_errors_are_loud(qa):
     with pytest.raises(ValueError):
         env.step(np.zeros((7, 4), np.float32))
     env.close()
+
+
+def test_two_ranks_on_one_gpu_equal_one_handle(qa, tmp_path):
+    """one process per shard (world_size 2, gloo for the gather, both ranks on cuda:0): the gathered roll-out
+    equals a single handle over all envs bit for bit -- the multi-GPU path minus RCCL."""
+    import os, socket, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "worker.py"
+    script.write_text('''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+import quadsim_amd as qa
+from quadsim_amd.distributed import env_shard, gather_rollout, rollout_global_view
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=2)
+rank = dist.get_rank()
+N, T = 2048, 48
+kw = dict(randomise=2, seed=77, init_range=(0.5, 0.1, 0.2, 0.1), mass_scale=(0.8, 1.2), inertia_scale=(0.8, 1.2))
+lo, n = env_shard(N)
+env = qa.VecDockingEnv("docking-v0", num_envs=n, env_id_offset=lo, **kw); env.reset()
+o, r, d, f = env.rollout(T=T)
+O, R, D = gather_rollout(o.cpu(), r.cpu(), d.cpu())
+if rank == 0:
+    one = qa.VecDockingEnv("docking-v0", num_envs=N, **kw); one.reset()
+    o1, r1, d1, f1 = one.rollout(T=T)
+    assert np.array_equal(rollout_global_view(O).numpy(), o1.cpu().numpy())
+    assert np.array_equal(rollout_global_view(R).numpy(), r1.cpu().numpy())
+    assert np.array_equal(rollout_global_view(D).numpy(), d1.cpu().numpy())
+    assert int(d1.sum()) > 100
+    print("OK")
+dist.destroy_process_group()
+''' % root)
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=300)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "OK" in outs[0]

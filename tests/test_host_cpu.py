@@ -1,0 +1,156 @@
+"""-m "not gpu": host logic, the C ABI's symbol table, and the world_size-2 sharding path on gloo."""
+import ctypes
+import os
+import re
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "quadsim.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(qs_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported_by_the_library():
+    """the C-ABI library loads on a GPU-less host and exports every symbol include/quadsim.h declares"""
+    from quadsim_amd import _lib
+    _lib.build_library()
+    lib = _lib.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 20
+    for name in declared:
+        assert hasattr(lib, name), "libquadsim_hip.so does not export %s" % name
+    assert sorted(_lib.EXPORTS) == declared
+    assert lib.qs_version() == 100
+
+
+def test_config_struct_matches_header():
+    from quadsim_amd import _lib
+    cfg = _lib.default_config()
+    assert cfg.struct_size == ctypes.sizeof(_lib.QsConfig)
+    assert (cfg.kind, cfg.num_envs, cfg.integrator, cfg.auto_reset, cfg.randomise) == (0, 1, 0, 0, 0)
+    assert abs(cfg.dt - 0.02) < 1e-9 and abs(cfg.mass - 0.18) < 1e-8
+    np.testing.assert_allclose(list(cfg.inertia), [0.00025, 0.000232, 0.0003738], rtol=1e-6)
+
+
+def test_no_gpu_fails_loudly_and_never_falls_back():
+    """without a HIP device every product entry point raises; nothing routes through the oracle"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import quadsim_amd as qa
+    with pytest.raises(qa.QuadsimError):
+        qa.VecDockingEnv("docking-v0", num_envs=4)
+    with pytest.raises(qa.QuadsimError):
+        qa.DockingEnv()
+    with pytest.raises(qa.QuadsimError):
+        qa.drone_step_batch(np.zeros((1, 13)), np.zeros((1, 4)), np.zeros((1, 4)))
+    # the product package never imports the oracle
+    for root, _, files in os.walk(os.path.join(ROOT, "quadsim_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+                assert "pyoracle" not in src and "libqso" not in src, f
+
+
+def test_shard_range_partitions_exactly():
+    from quadsim_amd import shard_range
+    for total, world in ((10, 4), (65536 * 4, 4), (1048576, 8), (7, 8), (1, 1)):
+        spans = [shard_range(total, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == total
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+    assert shard_range(262144, 3, 4) == (196608, 262144)
+    with pytest.raises(ValueError):
+        shard_range(8, 2, 2)
+
+
+def test_spaces_match_reference_bounds():
+    """docking_env.py:85-95"""
+    from quadsim_amd.spaces import docking_spaces
+    obs, act = docking_spaces()
+    assert obs.shape == (12,) and act.shape == (4,)
+    np.testing.assert_array_equal(act.low, -np.ones(4, np.float32))
+    np.testing.assert_allclose(obs.high[3:], [100, 100, 100, np.pi, np.pi / 2, np.pi, 10 * np.pi, 10 * np.pi, 10 * np.pi],
+                               rtol=1e-6)
+    assert np.all(np.isinf(obs.high[:3]))
+
+
+def test_attribute_surface_constants():
+    """what the reference scripts read off env.chaser (run_trained_docking_ppo2.py:45, run_expert_policy.py:41)"""
+    from quadsim_amd.drone import Drone
+    d = Drone()
+    L, lam = 0.086, 1.5e-9 / 6.11e-8
+    np.testing.assert_allclose(d.rotor2control, [[1, 1, 1, 1], [0, L, 0, -L], [-L, 0, L, 0], [lam, -lam, lam, -lam]])
+    assert d.get_arm_length() == 0.086 and d.get_mass() == 0.18 and d.dt == 0.02
+    # inverse action map of run_expert_policy.py:61 round-trips through rotor2control
+    u = np.array([1.9, 0.01, -0.02, 0.001])
+    mean = std = 0.18 * 9.81 / 2
+    a = (np.linalg.inv(d.rotor2control) @ u - mean) / std
+    np.testing.assert_allclose(d.rotor2control @ (std * a + mean), u, atol=1e-12)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_two_rank_gloo_sharded_rollout_matches_single_process(tmp_path):
+    """world_size 2 on gloo/CPU: each rank rolls out its env shard (oracle as the stand-in stepper, keyed by
+    GLOBAL env id), gathers the slabs with quadsim_amd.distributed.gather_rollout, and rank 0 checks the
+    global view equals a single-process roll-out of all envs bit for bit."""
+    script = tmp_path / "worker.py"
+    script.write_text('''
+import os, sys
+import numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, %r)
+from oracle.pyoracle import Oracle, PAR_NOMINAL
+from quadsim_amd.distributed import env_shard, gather_rollout, rollout_global_view
+
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+rank, world = dist.get_rank(), dist.get_world_size()
+N, T, seed = 96, 40, 5
+rr = (0.5, 0.1, 0.2, 0.1, 0.8, 1.2, 0.8, 1.2)
+orc = Oracle("f32")
+
+def roll(gid0, n):
+    rec = orc.env_init(n); par = np.tile(np.array(PAR_NOMINAL, np.float32), (n, 1))
+    orc.vec_reset(rec, par, randomise=2, seed=seed, step_idx=0, gid0=gid0, rr=rr)
+    rec[:, 39] = 570.0                      # every env times out inside the window -> resets exercised
+    acts = np.stack([[orc.random_action(seed, gid0 + i, t) for i in range(n)] for t in range(T)])
+    return orc.vec_rollout(rec, par, acts, kind=1, randomise=2, seed=seed, step_idx0=0, gid0=gid0, rr=rr)
+
+lo, n = env_shard(N)
+assert n == N // world and lo == rank * n
+o, r, d, f = roll(lo, n)
+O, R, D = gather_rollout(torch.from_numpy(o), torch.from_numpy(r), torch.from_numpy(d))
+if rank == 0:
+    o1, r1, d1, f1 = roll(0, N)
+    assert np.array_equal(rollout_global_view(O).numpy(), o1)
+    assert np.array_equal(rollout_global_view(R).numpy(), r1)
+    assert np.array_equal(rollout_global_view(D).numpy(), d1)
+    assert d1.sum() >= N
+    print("OK")
+dist.destroy_process_group()
+''' % ROOT)
+    port = _free_port()
+    procs = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(outs)
+    assert "OK" in outs[0]
