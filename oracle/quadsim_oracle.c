@@ -552,26 +552,29 @@ float FN(qso_u01)(uint32_t v)
 #define STREAM_RESET 1ull
 #define STREAM_ACTIONS 2ull
 
+/* (0,1) uniform from 16 random bits: (h + 1/2) / 65536, exact in binary32 */
+static float u16f(uint32_t h) { return fmaf((float)h, 1.52587890625e-05f, 7.62939453125e-06f); }
+
 /* Randomised initial state + per-episode params for env `gid` (global env id).
  * This is the build's own extension (the reference has no randomness in
  * v0/v2; the ranges are the commented-out lines docking_env.py:34-37).
  * rr[0..3] = half-ranges for chaser pos / vel / euler / body rates,
  * rr[4..5] = mass scale [lo,hi], rr[6..7] = inertia scale [lo,hi].
- * 16 uniforms = Philox blocks 4*ctr .. 4*ctr+3 of subsequence (stream<<48 | gid).
+ * 16 uniforms of 16 bits = the two Philox blocks 2*ctr, 2*ctr+1 of subsequence
+ * (stream<<48 | gid); u[2j] = low half, u[2j+1] = high half of word j.
  * All arithmetic in binary32 with explicit fmaf so that HIP == CPU bit for bit
  * up to the euler2quat sin/cos (compared to tolerance). */
 void FN(qso_random_init)(uint64_t seed, uint64_t stream, uint64_t gid, uint64_t ctr,
                          const float rr[8], const float par_nom[4],
                          float sc[13], float st[13], float par[4], float u16[16])
 {
-    uint32_t w[16];
+    uint32_t w[8];
     float u[16];
     int i;
-    for (i = 0; i < 4; ++i)
-        FN(qso_philox4x32_10)(seed, (stream << 48) | gid, 4ull * ctr + (uint64_t)i, w + 4 * i);
-    for (i = 0; i < 16; ++i) u[i] = FN(qso_u01)(w[i]);
+    for (i = 0; i < 2; ++i)
+        FN(qso_philox4x32_10)(seed, (stream << 48) | gid, 2ull * ctr + (uint64_t)i, w + 4 * i);
+    for (i = 0; i < 8; ++i) { u[2 * i] = u16f(w[i] & 0xFFFFu); u[2 * i + 1] = u16f(w[i] >> 16); }
     if (u16) for (i = 0; i < 16; ++i) u16[i] = u[i];
-    /* symmetric: x = nominal + (2u-1)*range */
     float e[3];
     for (i = 0; i < 13; ++i) { sc[i] = 0; st[i] = 0; }
     sc[0] = fmaf(fmaf(2.0f, u[0], -1.0f), rr[0], 8.0f);

@@ -119,6 +119,16 @@ __device__ __forceinline__ void q_sincos(float x, float &sn, float &cs)
     cs = __uint_as_float(__float_as_uint(cc) ^ (((unsigned)(k + 1) & 2u) << 30));
 }
 
+// sin and cos for |x| <= pi/4 (no reduction, no quadrant logic): the same polynomials as q_sincos
+__device__ __forceinline__ void q_sincos_small(float r, float &sn, float &cs)
+{
+    float z = r * r;
+    float sp = fmaf(fmaf(-0.0001958291686605662f, z, 0.008332724682986736f), z, -0.166666641831398f);
+    sn = fmaf(r * z, sp, r);
+    float cp = fmaf(fmaf(2.4542947357986122e-05f, z, -0.0013888279208913445f), z, 0.0416666641831398f);
+    cs = fmaf(z * z, cp, fmaf(-0.5f, z, 1.0f));
+}
+
 // off-diagonal entries of the reference's quat2rot (diagonal is identically 1):
 // utils/transform.py:4-20 == dynamics/quadrotor.py:226-245.  Element-wise
 // qa_hat*qa_hat with the NORMALISED vector part, linear term with the
@@ -364,10 +374,13 @@ __device__ __forceinline__ void target_control(int mode, const float pdes[3], co
 
 // dock-port states (dynamics/quadrotor.py:213-224) + state2rel (docking_env.py:257-295).
 // Ports are (+0.1,0,0) on the chaser and (-0.1,0,0) on the target (docking_env.py:38,51).
+// TARGET_LEVEL: the target's attitude is the identity quaternion (every reset state): R_I2B = I folds away.
+template <bool TARGET_LEVEL = false>
 __device__ __forceinline__ void rel_obs(const float sc[13], const float st[13], float o[12])
 {
     Rot A = quat2rot(sc + 6);   // R_I2A
-    Rot B = quat2rot(st + 6);   // R_I2B
+    Rot B = {0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
+    if (!TARGET_LEVEL) B = quat2rot(st + 6);   // R_I2B
     // port offsets in the world frame: R^T port = port_x * (1, r01, r02)
     float bc0 = 0.1f, bc1 = 0.1f * A.r01, bc2 = 0.1f * A.r02;
     float bt0 = -0.1f, bt1 = -0.1f * B.r01, bt2 = -0.1f * B.r02;
@@ -434,6 +447,9 @@ __device__ __forceinline__ void nominal_init(float sc[13], float st[13])
 // (0,1] uniform from 32 random bits: one fused multiply-add, pinned identically in the oracle
 __device__ __forceinline__ float u01(unsigned v) { return __fmaf_rn((float)v, 2.3283064e-10f, 2.3283064e-10f); }
 __device__ __forceinline__ float sym(float u) { return __fmaf_rn(2.0f, u, -1.0f); }
+// (0,1) uniform from 16 random bits, (h + 1/2) / 65536: exact in binary32
+__device__ __forceinline__ float u16lo(unsigned w) { return __fmaf_rn((float)(w & 0xFFFFu), 1.52587890625e-05f, 7.62939453125e-06f); }
+__device__ __forceinline__ float u16hi(unsigned w) { return __fmaf_rn((float)(w >> 16), 1.52587890625e-05f, 7.62939453125e-06f); }
 
 struct RandCfg {
     uint64_t seed;
@@ -449,35 +465,43 @@ __device__ __forceinline__ uint4 philox_block(uint64_t seed, uint64_t stream, ui
     return rocrand4(&rs);
 }
 
-// randomised initial state (+ per-episode params): 16 uniforms = blocks 4*ctr..4*ctr+3.
+// randomised initial state (+ per-episode params): 16 uniforms of 16 bits = the two Philox blocks
+// 2*ctr, 2*ctr+1 (a reset sits on the step's critical path; 16 bits resolve 0.5 m to 8 um).
+// u[2j] = low half, u[2j+1] = high half of word j.  Half-angles stay below pi/4 (qs_create checks
+// init_range[2] <= pi/2), so the reduction-free sincos applies.
 // Build extension; the reference's v0/v2 have no randomness.
 template <bool WITH_PAR>
 __device__ __forceinline__ void random_init(const RandCfg &rc, uint64_t stream, uint64_t gid, uint64_t ctr,
                                             float sc[13], float st[13], Par &P)
 {
-    uint4 w0 = philox_block(rc.seed, stream, gid, 4ull * ctr + 0);
-    uint4 w1 = philox_block(rc.seed, stream, gid, 4ull * ctr + 1);
-    uint4 w2 = philox_block(rc.seed, stream, gid, 4ull * ctr + 2);
-    uint4 w3 = make_uint4(0u, 0u, 0u, 0u);
-    if (WITH_PAR) w3 = philox_block(rc.seed, stream, gid, 4ull * ctr + 3);
+    uint4 w0 = philox_block(rc.seed, stream, gid, 2ull * ctr + 0);
+    uint4 w1 = philox_block(rc.seed, stream, gid, 2ull * ctr + 1);
     nominal_init(sc, st);
-    sc[0] = __fmaf_rn(sym(u01(w0.x)), rc.rr[0], 8.0f);
-    sc[1] = __fmaf_rn(sym(u01(w0.y)), rc.rr[0], -50.0f);
-    sc[2] = __fmaf_rn(sym(u01(w0.z)), rc.rr[0], 5.0f);
-    sc[3] = sym(u01(w0.w)) * rc.rr[1];
-    sc[4] = sym(u01(w1.x)) * rc.rr[1];
-    sc[5] = sym(u01(w1.y)) * rc.rr[1];
-    float e0 = sym(u01(w1.z)) * rc.rr[2];
-    float e1 = sym(u01(w1.w)) * rc.rr[2];
-    float e2 = sym(u01(w2.x)) * rc.rr[2];
-    euler2quat(e0, e1, e2, sc + 6);
-    sc[10] = sym(u01(w2.y)) * rc.rr[3];
-    sc[11] = sym(u01(w2.z)) * rc.rr[3];
-    sc[12] = sym(u01(w2.w)) * rc.rr[3];
-    P.m = rc.par_nom[0] * __fmaf_rn(rc.rr[5] - rc.rr[4], u01(w3.x), rc.rr[4]);
-    P.Ixx = rc.par_nom[1] * __fmaf_rn(rc.rr[7] - rc.rr[6], u01(w3.y), rc.rr[6]);
-    P.Iyy = rc.par_nom[2] * __fmaf_rn(rc.rr[7] - rc.rr[6], u01(w3.z), rc.rr[6]);
-    P.Izz = rc.par_nom[3] * __fmaf_rn(rc.rr[7] - rc.rr[6], u01(w3.w), rc.rr[6]);
+    sc[0] = __fmaf_rn(sym(u16lo(w0.x)), rc.rr[0], 8.0f);
+    sc[1] = __fmaf_rn(sym(u16hi(w0.x)), rc.rr[0], -50.0f);
+    sc[2] = __fmaf_rn(sym(u16lo(w0.y)), rc.rr[0], 5.0f);
+    sc[3] = sym(u16hi(w0.y)) * rc.rr[1];
+    sc[4] = sym(u16lo(w0.z)) * rc.rr[1];
+    sc[5] = sym(u16hi(w0.z)) * rc.rr[1];
+    float e0 = sym(u16lo(w0.w)) * rc.rr[2];
+    float e1 = sym(u16hi(w0.w)) * rc.rr[2];
+    float e2 = sym(u16lo(w1.x)) * rc.rr[2];
+    float sr, cr, sp, cp, sy, cy;
+    q_sincos_small(0.5f * e0, sr, cr);
+    q_sincos_small(0.5f * e1, sp, cp);
+    q_sincos_small(0.5f * e2, sy, cy);
+    euler2quat_trig(sr, cr, sp, cp, sy, cy, sc + 6);
+    sc[10] = sym(u16hi(w1.x)) * rc.rr[3];
+    sc[11] = sym(u16lo(w1.y)) * rc.rr[3];
+    sc[12] = sym(u16hi(w1.y)) * rc.rr[3];
+    if (WITH_PAR) {
+        P.m = rc.par_nom[0] * __fmaf_rn(rc.rr[5] - rc.rr[4], u16lo(w1.z), rc.rr[4]);
+        P.Ixx = rc.par_nom[1] * __fmaf_rn(rc.rr[7] - rc.rr[6], u16hi(w1.z), rc.rr[6]);
+        P.Iyy = rc.par_nom[2] * __fmaf_rn(rc.rr[7] - rc.rr[6], u16lo(w1.w), rc.rr[6]);
+        P.Izz = rc.par_nom[3] * __fmaf_rn(rc.rr[7] - rc.rr[6], u16hi(w1.w), rc.rr[6]);
+    } else {
+        P = Par{rc.par_nom[0], rc.par_nom[1], rc.par_nom[2], rc.par_nom[3]};
+    }
 }
 
 __device__ __forceinline__ void random_action(uint64_t seed, uint64_t gid, uint64_t k, float a[4])
@@ -534,6 +558,7 @@ __device__ __forceinline__ void env_step(Env &e, const float a[4], const Par &P,
 
 // DockingEnv.reset (docking_env.py:233-244) + Drone.reset (quadrotor.py:65-78):
 // new initial states, stored controls, t and last_shaping zeroed, q_des untouched.
+template <bool TARGET_LEVEL = false>
 __device__ __forceinline__ void env_reset(Env &e, const float ic[13], const float it[13], float obs[12])
 {
 #pragma unroll
@@ -542,7 +567,7 @@ __device__ __forceinline__ void env_reset(Env &e, const float ic[13], const floa
     for (int i = 0; i < 4; ++i) { e.uc[i] = 0.0f; e.ut[i] = 0.0f; }
     e.ls = 0.0f;
     e.t = 0.0f;
-    rel_obs(e.sc, e.st, obs);
+    rel_obs<TARGET_LEVEL>(e.sc, e.st, obs);
 }
 
 }  // namespace qs

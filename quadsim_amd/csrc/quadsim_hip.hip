@@ -129,7 +129,7 @@ __device__ __forceinline__ void step_and_maybe_reset(Env &e, Par &P, const float
             Par Pn;
             random_init<RMODE >= 2>(A.rc, STREAM_AUTORESET, A.gid0 + (uint64_t)env, k + 1, ic, it, Pn);
             if (PARAMS && RMODE >= 2) P = Pn;
-            env_reset(e, ic, it, obs);
+            env_reset<true>(e, ic, it, obs);   // reset states always have a level target
         }
     }
 }
@@ -499,6 +499,8 @@ int qs_create(const QsConfig *cfg, QsEnv **out)
     if (cfg->integrator != QS_INTEG_FROZEN && cfg->integrator != QS_INTEG_RK4) return fail(QS_ERR_INVALID, "qs_create: unknown integrator %d", cfg->integrator);
     if (cfg->randomise < 0 || cfg->randomise > 2) return fail(QS_ERR_INVALID, "qs_create: randomise must be 0..2");
     if (cfg->io_space != QS_IO_DEVICE && cfg->io_space != QS_IO_HOST) return fail(QS_ERR_INVALID, "qs_create: bad io_space");
+    if (cfg->randomise && !(cfg->init_range[2] >= 0.0f && cfg->init_range[2] <= 1.5707964f))
+        return fail(QS_ERR_INVALID, "qs_create: init_range[2] (euler half-range) must be within [0, pi/2]");
     if (!(cfg->dt > 0.0f) || !(cfg->mass > 0.0f) || !(cfg->inertia[0] > 0.0f) || !(cfg->inertia[1] > 0.0f) || !(cfg->inertia[2] > 0.0f))
         return fail(QS_ERR_INVALID, "qs_create: dt, mass and inertia must be positive");
     int ndev = 0;

@@ -165,4 +165,5 @@ def test_random_init_ranges(oracle64):
         np.testing.assert_array_equal(st, [10, -50, 5, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0])
         assert 0.8 * 0.18 <= par[0] <= 1.2 * 0.18 * (1 + 1e-6)
     U = np.array(U)
-    assert U.min() > 0 and U.max() <= 1 and abs(U.mean() - 0.5) < 0.02 and abs(U.var() - 1 / 12) < 0.01
+    assert U.min() > 0 and U.max() < 1 and abs(U.mean() - 0.5) < 0.02 and abs(U.var() - 1 / 12) < 0.01
+    assert np.all(U * 65536 - 0.5 == np.round(U * 65536 - 0.5))        # 16-bit lattice (h + 1/2) / 65536
