@@ -1,0 +1,45 @@
+"""Policy-in-the-loop roll-outs on the device.
+
+``MlpPolicy`` is the deterministic actor of the PPO2 model the reference ships
+(`trained_model/best_model_v0.zip`: shared_fc0 12->128, pi_fc0 128->128, pi 128->4,
+ReLU, actions clipped to [-1, 1]) as `run_trained_docking_ppo2.py:37-45` uses it:
+``action, _ = model.predict(obs, deterministic=True); env.step(action)``.
+The three GEMMs are plain library GEMMs (torch -> hipBLASLt); the env step is the
+fused HIP kernel.  The loop never leaves the GPU: no host sync between steps.
+"""
+import numpy as np
+
+
+class MlpPolicy:
+    def __init__(self, weights, device="cuda"):
+        import torch
+        self.torch = torch
+        g = lambda k: torch.as_tensor(np.asarray(weights[k], np.float32)).to(device)  # noqa: E731
+        self.w0, self.b0 = g("w0"), g("b0")
+        self.w1, self.b1 = g("w1"), g("b1")
+        self.w2, self.b2 = g("w2"), g("b2")
+
+    @classmethod
+    def from_npz(cls, path, device="cuda"):
+        with np.load(path, allow_pickle=False) as z:
+            return cls({k: z[k] for k in z.files}, device)
+
+    def predict(self, obs):
+        """obs [N,12] float32 (device) -> actions [N,4] in [-1,1]"""
+        t = self.torch
+        h = t.relu(t.addmm(self.b0, obs, self.w0))
+        h = t.relu(t.addmm(self.b1, h, self.w1))
+        return t.clamp(t.addmm(self.b2, h, self.w2), -1.0, 1.0)
+
+
+def rollout_with_policy(env, policy, T, obs0=None):
+    """T steps of ``a = policy(obs); obs, r, d, info = env.step(a)`` on a torch-backend VecDockingEnv.
+    Returns stacked (obs [T,N,12], reward [T,N], done [T,N] bool, flags [T,N] u8, actions [T,N,4])."""
+    import torch
+    obs = env.reset() if obs0 is None else obs0
+    O, R, D, F, A = [], [], [], [], []
+    for _ in range(T):
+        a = policy.predict(obs)
+        obs, r, d, info = env.step(a)
+        O.append(obs.clone()); R.append(r.clone()); D.append(d.clone()); F.append(env._flags.clone()); A.append(a)
+    return torch.stack(O), torch.stack(R), torch.stack(D), torch.stack(F), torch.stack(A)

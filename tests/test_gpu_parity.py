@@ -403,3 +403,23 @@ dist.destroy_process_group()
     outs = [p.communicate(timeout=300)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "OK" in outs[0]
+
+
+def test_policy_in_the_loop_reaches_docked_state(qa):
+    """run_trained_docking_ppo2.py:36-60 on the GPU: the shipped PPO2 actor (weights fixture) drives docking-v0
+    for a full episode.  Closed loop from reset: the reference episode docks for 183 steps, ends by time-out at
+    t = 600 with return 0.7071 (fixture g5).  fp32 closed-loop drift over 600 steps is held to 2e-3."""
+    import os
+    from conftest import GOLDEN
+    g = load_golden("g5_policy_episode")
+    pol = qa.MlpPolicy.from_npz(os.path.join(GOLDEN, "policy_best_model_v0.npz"))
+    env = qa.VecDockingEnv("docking-v0", num_envs=8, auto_reset=True)
+    O, R, D, F, A = qa.rollout_with_policy(env, pol, 600)
+    O, R, D, F, A = (x.cpu().numpy() for x in (O, R, D, F, A))
+    env.close()
+    assert np.all(O[:, 0] == O[:, 7]) and np.all(A[:, 0] == A[:, 7])           # identical envs stay identical
+    np.testing.assert_allclose(A[:, 0], g["actions"], atol=5e-3)
+    np.testing.assert_allclose(O[:599, 0], g["obs"][:599], atol=2e-3)
+    assert abs(float(R[:, 0].sum()) - float(g["reward"].sum())) < 5e-3
+    assert abs(int((F[:, 0] & 1).sum()) - 183) <= 3
+    assert bool(D[599, 0]) and not D[:599, 0].any() and (F[599, 0] & 4)
