@@ -24,6 +24,7 @@
  *   state vector [13] = pos(3) vel(3) quat w,x,y,z(4) body-rates(3)   (dynamics/quadrotor.py:25)
  *   actions [N,4] in [-1,1]                                             (docking_env.py:93)
  *   obs [N,12] = rel_pos rel_vel rel_euler rel_euler_rates              (docking_env.py:287-293)
+ *   (hovering-v0: obs [N,13] = the drone's state, hovering_env.py:78; read `12` as qs_obs_dim below)
  *   done [N] uint8; flags [N] uint8 (QS_FLAG_*)
  */
 #ifndef QUADSIM_H
@@ -48,7 +49,10 @@ enum {
 /* env kinds: gym ids registered at gym-docking/gym_docking/__init__.py:3-17 */
 enum {
     QS_KIND_DOCKING_V0 = 0, /* DockingEnv,       envs/docking_env.py        */
-    QS_KIND_DOCKING_V2 = 1  /* MovingDockingEnv, envs/moving_docking_env.py */
+    QS_KIND_DOCKING_V2 = 1, /* MovingDockingEnv, envs/moving_docking_env.py */
+    QS_KIND_DOCKING_V1 = 2, /* ImitatingDockingEnv, envs/imitating_docking_env.py: v0 whose chaser start is jittered
+                               once at construction (:34) and restored by every reset */
+    QS_KIND_HOVERING_V0 = 3 /* HoveringEnv, envs/hovering_env.py: one drone, obs = raw state [13], action in [0,1]^4 */
 };
 
 enum {
@@ -149,6 +153,18 @@ int qs_get_state(QsEnv *env, float *chaser, float *target, float *u_prev, float 
                  float *t);
 int qs_set_state(QsEnv *env, const float *chaser, const float *target, const float *u_prev, const float *qdes,
                  const float *last_shaping, const float *t);
+
+/* Per-env initial states that reset() (and the auto-reset) return to: env.chaser_ini_state / env.target_ini_state
+ * (docking_env.py:39-57; scripts mutate them, run_expert_policy.py:44,63-64) or HoveringEnv.ini_state
+ * (hovering_env.py:26-29).  chaser_init [N,13]; target_init [N,13] nullable = nominal (ignored for hovering).
+ * docking-v1 and hovering-v0 handles are created with rocRAND-drawn per-env initial states (the reference draws
+ * them from numpy's global RNG at construction); this call overrides them.  Switches the handle to stored-init
+ * resets (takes precedence over `randomise`) and re-initialises nothing by itself: call qs_reset afterwards. */
+int qs_set_init_state(QsEnv *env, const float *chaser_init, const float *target_init);
+int qs_get_init_state(QsEnv *env, float *chaser_init, float *target_init);
+
+/* width of an observation row: 12 for the docking envs, 13 for hovering-v0 */
+int qs_obs_dim(QsEnv *env, int32_t *dim);
 
 /* per-env mass [N] and diagonal inertia [N,3] (Drone.mass / Drone.Inertia; also sets F_max = 4 m g,
  * controller.mass and action_mean/std = m g / 2 consistently).  Switches the handle to per-env params. */

@@ -18,6 +18,8 @@ Fixture sets:
   g5_policy_episode v0 episode driven by trained_model/best_model_v0.zip (reaches the docked state)
   g6_sim_pid        run_sim_PID.py:8-54 hover loop, 2000 steps (BASELINE config 1)
   g7_domain_rand    v0/v2 trajectories with patched mass / inertia
+  g8_traj_v1        docking-v1 (construction-time chaser jitter) trajectories, three constructions
+  g9_hovering       hovering-v0 trajectories (raw-state obs, own reward/done), three constructions
 """
 import importlib.util
 import io
@@ -338,7 +340,88 @@ def gen_g7(T=400):
     save("g7_domain_rand", **out)
 
 
+def gen_g8(T=900):
+    """docking-v1 (imitating_docking_env.py): v0 + chaser position jitter drawn ONCE at construction"""
+    v1 = importlib.util.spec_from_file_location(
+        "ref_imitating_docking_env", os.path.join(REF, "gym-docking/gym_docking/envs/imitating_docking_env.py"))
+    mod = importlib.util.module_from_spec(v1); v1.loader.exec_module(mod)
+    out = {}
+    for j, seed in enumerate((11, 12, 13)):
+        np.random.seed(seed)                    # the ctor uses the global numpy RNG (:34)
+        env = mod.ImitatingDockingEnv()
+        rs = np.random.RandomState(800 + j)
+        actions = mixed_actions(rs, T, block=300)
+        tr = run_traj(env, actions)
+        key = "e%d_" % j
+        out[key + "chaser_ini_state"] = np.array(env.chaser_ini_state)
+        out[key + "target_ini_state"] = np.array(env.target_ini_state)
+        out[key + "actions"] = actions
+        for k in ("first_obs", "rec_before", "rec_after", "obs", "reward", "done", "flags", "reset_obs"):
+            out[key + k] = tr[k]
+        assert np.max(np.abs(env.chaser_ini_state[0:3] - [8, -50, 5])) <= 0.3
+    print("g8: episodes", [int(out["e%d_done" % j].sum()) for j in range(3)])
+    save("g8_traj_v1", **out)
+
+
+def gen_g9(T=1200):
+    """hovering-v0 (hovering_env.py): one drone, raw-state obs, own reward/done; ini_state drawn at construction"""
+    hv = importlib.util.spec_from_file_location(
+        "ref_hovering_env", os.path.join(REF, "gym-docking/gym_docking/envs/hovering_env.py"))
+    mod = importlib.util.module_from_spec(hv); hv.loader.exec_module(mod)
+    out = {}
+    for j, seed in enumerate((21, 22, 23)):
+        np.random.seed(seed)
+        env = mod.HoveringEnv()
+        rs = np.random.RandomState(900 + j)
+        a = np.zeros((T, 4), np.float32)
+        for b0 in range(0, T, 200):            # blocks: U(0,1), near-hover (0.25 = weight/4 per rotor), full thrust
+            m = (b0 // 200) % 3
+            a[b0:b0 + 200] = (rs.uniform(0, 1, (200, 4)) if m == 0 else
+                              np.clip(0.25 + 0.02 * rs.randn(200, 4), 0, 1) if m == 1 else
+                              np.clip(0.9 + 0.1 * rs.randn(200, 4), 0, 1))
+        if j == 2:
+            a[:] = np.clip(0.97 + 0.03 * rs.randn(T, 4), 0, 1)    # climbs away: reaches the done branch (|pos| > 100)
+        s = np.array(env.reset(), dtype=np.float64)
+        SB, UB, SA, UA, R, D = [], [], [], [], [], []
+        for t in range(T):
+            SB.append(np.array(env.drone.state, dtype=np.float64)); UB.append(np.array(env.drone.u))
+            o, r, d, _ = env.step(a[t].astype(np.float64))
+            SA.append(np.array(o, dtype=np.float64)); UA.append(np.array(env.drone.u)); R.append(r); D.append(d)
+            if d:
+                env.reset()
+        key = "e%d_" % j
+        out[key + "ini_state"] = np.array(env.ini_state)
+        out[key + "actions"] = a
+        out[key + "state_before"] = np.array(SB); out[key + "u_before"] = np.array(UB)
+        out[key + "state_after"] = np.array(SA); out[key + "u_after"] = np.array(UA)
+        out[key + "reward"] = np.array(R); out[key + "done"] = np.array(D, np.uint8)
+    # crafted single steps around the +1 bonus ball (|pos err| < 0.1 and |vel| < 0.1, hovering_env.py:63)
+    np.random.seed(24)
+    env = mod.HoveringEnv()
+    rs = np.random.RandomState(950)
+    SB, UB, A, SA, UA, R, D, M = [], [], [], [], [], [], [], []
+    while len(SB) < 300:
+        s = np.zeros(13)
+        s[0:3] = np.array([0, 0, 5.0]) + rs.normal(0, 0.06, 3)
+        s[3:6] = rs.normal(0, 0.06, 3)
+        s[6:10] = transform.euler2quat(rs.uniform(-0.3, 0.3, 3))
+        s[10:13] = rs.normal(0, 0.3, 3)
+        up = np.array([0.18 * 9.81 + rs.normal(0, 0.2), *rs.normal(0, 2, 3)])
+        a = np.clip(0.25 + 0.1 * rs.randn(4), 0, 1).astype(np.float32)
+        set_drone(env.drone, s, up)
+        o, r, d, _ = env.step(a.astype(np.float64))
+        o = np.array(o, dtype=np.float64)
+        margin = min(abs(np.linalg.norm(o[0:3] - [0, 0, 5]) - 0.1), abs(np.linalg.norm(o[3:6]) - 0.1))
+        SB.append(s); UB.append(up); A.append(a); SA.append(o); UA.append(np.array(env.drone.u)); R.append(r); D.append(d); M.append(margin)
+    out.update(c_state_before=np.array(SB), c_u_before=np.array(UB), c_actions=np.array(A), c_state_after=np.array(SA),
+               c_u_after=np.array(UA), c_reward=np.array(R), c_done=np.array(D, np.uint8), c_margin=np.array(M))
+    print("g9: crafted bonus steps", int((np.array(R) > 1.0).sum()), "of", len(R))
+    print("g9: done counts", [int(out["e%d_done" % j].sum()) for j in range(3)],
+          "bonus steps", [int((out["e%d_reward" % j] > 1.0).sum()) for j in range(3)])
+    save("g9_hovering", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     for w in which:
         globals()["gen_" + w]()

@@ -180,6 +180,45 @@ class Oracle:
                                    _p(obs), _p(rew), _p(done), _p(flags))
         return obs, rew, done, flags
 
+    def vec_step_stored_init(self, rec, par, actions, init, kind=0, dt=0.02, integ=0, auto_reset=True,
+                             want_term=False):
+        """docking-v1 style: reset returns to init[N,26] (chaser_ini_state, target_ini_state)"""
+        n = rec.shape[0]
+        actions = self._a(actions, (n, 4)); init = self._a(init, (n, 26))
+        obs = np.zeros((n, 12), self.dtype); rew = np.zeros(n, self.dtype)
+        done = np.zeros(n, np.uint8); flags = np.zeros(n, np.uint8)
+        term = np.full((n, 12), np.nan, self.dtype) if want_term else None
+        self._f("qso_vec_step_stored_init")(C.c_int64(n), _p(rec), _p(par), _p(actions), C.c_int(kind),
+                                            self.creal(dt), C.c_int(integ), C.c_int(int(auto_reset)), _p(init),
+                                            _p(obs), _p(rew), _p(done), _p(flags), _p(term))
+        return obs, rew, done, flags, term
+
+    def hover_step(self, s, u_prev, a, par=PAR_NOMINAL, dt=0.02, integ=0):
+        """single HoveringEnv.step -> (state', u_prev', reward, done, flags)"""
+        s = self._a(s, (13,)).copy(); up = self._a(u_prev, (4,)).copy(); a = self._a(a, (4,)); par = self._a(par, (4,))
+        rew = self.creal(0); done = C.c_int(0); flags = C.c_int(0)
+        self._f("qso_hover_step")(_p(s), _p(up), _p(a), _p(par), self.creal(dt), C.c_int(integ),
+                                  C.byref(rew), C.byref(done), C.byref(flags))
+        return s, up, float(rew.value), bool(done.value), int(flags.value)
+
+    def hover_vec_step(self, st, par, actions, init, dt=0.02, integ=0, auto_reset=True, want_term=False):
+        """st [N,17] in place -> (obs[N,13], reward, done, flags, term)"""
+        n = st.shape[0]
+        assert st.dtype == self.dtype and st.shape == (n, 17) and st.flags.c_contiguous
+        actions = self._a(actions, (n, 4)); init = self._a(init, (n, 13)); par = self._a(par, (n, 4))
+        obs = np.zeros((n, 13), self.dtype); rew = np.zeros(n, self.dtype)
+        done = np.zeros(n, np.uint8); flags = np.zeros(n, np.uint8)
+        term = np.full((n, 13), np.nan, self.dtype) if want_term else None
+        self._f("qso_hover_vec_step")(C.c_int64(n), _p(st), _p(par), _p(actions), self.creal(dt), C.c_int(integ),
+                                      C.c_int(int(auto_reset)), _p(init), _p(obs), _p(rew), _p(done), _p(flags), _p(term))
+        return obs, rew, done, flags, term
+
+    def ctor_init(self, seed, gid, kind):
+        """construction-time jittered initial state: kind 2 -> [26], kind 3 -> [13] (float32)"""
+        out = np.zeros(26 if kind == 2 else 13, np.float32)
+        self._f("qso_ctor_init")(C.c_uint64(seed), C.c_uint64(gid), C.c_int(kind), _p(out))
+        return out
+
     def sim_pid(self, T, s, sdes, par=PAR_NOMINAL, dt=0.02, integ=0, u_prev=None):
         """run_sim_PID.py:43-54 loop -> (states[T,13], u[T,4], final state, final sdes)"""
         s = self._a(s, (13,)).copy(); sdes = self._a(sdes, (13,)).copy(); par = self._a(par, (4,))

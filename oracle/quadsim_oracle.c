@@ -706,4 +706,128 @@ void FN(qso_sim_pid)(int64_t T, real s[13], real u_prev[4], real sdes[13], const
     }
 }
 
+/* -------------------------------------------------------------------------
+ * docking-v1 and hovering-v0
+ * ---------------------------------------------------------------------- */
+
+/* Vector driver for envs whose reset returns to a STORED per-env initial state:
+ * docking-v1 = docking-v0 whose chaser start is jittered once at construction
+ * (imitating_docking_env.py:34) and restored by every reset() (:193-204); also the
+ * script-mutated env.chaser_ini_state case (run_expert_policy.py:44,63-64).
+ * init [N][26] = chaser_ini_state, target_ini_state. */
+void FN(qso_vec_step_stored_init)(int64_t N, real *rec, const real *par, const real *actions, int kind, real dt,
+                                  int integ, int auto_reset, const real *init,
+                                  real *obs, real *reward, uint8_t *done, uint8_t *flags, real *term_obs)
+{
+    int64_t i;
+    for (i = 0; i < N; ++i) {
+        real *r = rec + i * REC_LEN;
+        real rew; int d, f, j;
+        FN(qso_env_step)(r, actions + 4 * i, par + 4 * i, kind, dt, integ, obs + 12 * i, &rew, &d, &f);
+        reward[i] = rew; done[i] = (uint8_t)d; flags[i] = (uint8_t)f;
+        if (d && auto_reset) {
+            if (term_obs) for (j = 0; j < 12; ++j) term_obs[12 * i + j] = obs[12 * i + j];
+            FN(qso_env_reset)(r, init + 26 * i, init + 26 * i + 13, obs + 12 * i);
+        }
+    }
+}
+
+/* HoveringEnv.step, gym-docking/gym_docking/envs/hovering_env.py:47-78.
+ * One drone; action in [0,1]^4 scaled by action_max = m g (:42,:51); obs = raw state;
+ * reward :62-76; done :68.  state_des = (0,0,5, 0.., quat identity, 0..) (:31-35).
+ * flags: bit0 = inside the +1 bonus ball (:63), bit3 = attitude limiter fired. */
+void FN(qso_hover_step)(real s[13], real u_prev[4], const real a[4], const real par[4], real dt, int integ,
+                        real *reward, int *done, int *flags)
+{
+    real mass = par[0];
+    real lambda = (real)(K_KM / K_KF);
+    real amax = (real)1.0 * mass * K_G;                       /* :42 */
+    real f0 = amax * a[0], f1 = amax * a[1], f2 = amax * a[2], f3 = amax * a[3];
+    real u[4];
+    u[0] = f0 + f1 + f2 + f3;                                 /* rotor2control @ (.), :51 */
+    u[1] = 0 * f0 + K_L * f1 + 0 * f2 + (-K_L) * f3;
+    u[2] = (-K_L) * f0 + 0 * f1 + K_L * f2 + 0 * f3;
+    u[3] = lambda * f0 + (-lambda) * f1 + lambda * f2 + (-lambda) * f3;
+    int lim = FN(qso_drone_step)(s, u_prev, u, par, dt, integ);   /* :52 */
+    real pe0 = 0 - s[0], pe1 = 0 - s[1], pe2 = (real)5.0 - s[2];  /* :57, state_des :31 */
+    real ve0 = 0 - s[3], ve1 = 0 - s[4], ve2 = 0 - s[5];          /* :58 */
+    const real qd[4] = {1, 0, 0, 0};
+    real ed[3], en[3];
+    FN(qso_quat2euler)(qd, ed);                               /* :59 */
+    FN(qso_quat2euler)(s + 6, en);
+    real ae0 = ed[0] - en[0], ae1 = ed[1] - en[1], ae2 = ed[2] - en[2];
+    real we0 = 0 - s[10], we1 = 0 - s[11], we2 = 0 - s[12];   /* :60 */
+    real npe = R_SQRT(pe0 * pe0 + pe1 * pe1 + pe2 * pe2), nve = R_SQRT(ve0 * ve0 + ve1 * ve1 + ve2 * ve2);
+    real nae = R_SQRT(ae0 * ae0 + ae1 * ae1 + ae2 * ae2), nwe = R_SQRT(we0 * we0 + we1 * we1 + we2 * we2);
+    int inside = (npe < (real)0.1) && (nve < (real)0.1);      /* :63 */
+    real r_thre = inside ? (real)1.0 : (real)0.0;
+    int d = (R_SQRT(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]) > (real)100.0)
+            || (R_SQRT(s[3] * s[3] + s[4] * s[4] + s[5] * s[5]) > (real)100.0);   /* :68 */
+    if (!d)
+        *reward = r_thre + (real)0.1 - (real)0.01 * npe - (real)0.001 * nve - (real)0.01 * nae - (real)0.001 * nwe;  /* :71-74 */
+    else
+        *reward = (real)-0.1;                                 /* :76 */
+    *done = d;
+    *flags = (inside ? 1 : 0) | (d ? 2 : 0) | (lim ? 8 : 0);
+}
+
+/* vector hovering env with VecEnv auto-reset to the stored per-env ini_state
+ * (hovering_env.py:80-82: reset() -> Drone.reset(ini_state): state restored, u zeroed).
+ * st [N][17] = state 13 + last limited control 4; init [N][13]; obs [N][13] = state after step (or reset). */
+void FN(qso_hover_vec_step)(int64_t N, real *st, const real *par, const real *actions, real dt, int integ,
+                            int auto_reset, const real *init, real *obs, real *reward, uint8_t *done,
+                            uint8_t *flags, real *term_obs)
+{
+    int64_t i; int j;
+    for (i = 0; i < N; ++i) {
+        real *s = st + 17 * i;
+        real rew; int d, f;
+        FN(qso_hover_step)(s, s + 13, actions + 4 * i, par + 4 * i, dt, integ, &rew, &d, &f);
+        reward[i] = rew; done[i] = (uint8_t)d; flags[i] = (uint8_t)f;
+        if (d && auto_reset) {
+            if (term_obs) for (j = 0; j < 13; ++j) term_obs[13 * i + j] = s[j];
+            for (j = 0; j < 13; ++j) s[j] = init[13 * i + j];
+            for (j = 0; j < 4; ++j) s[13 + j] = 0;
+        }
+        for (j = 0; j < 13; ++j) obs[13 * i + j] = s[j];
+    }
+}
+
+#define STREAM_INIT 3ull
+/* construction-time jitter (stream INIT, ctr 0): kind 2 (docking-v1) chaser pos += U(-0.3,0.3)^3
+ * (imitating_docking_env.py:34); kind 3 (hovering-v0) pos = (0,0,5) + U(-1,1)^3,
+ * att = euler2quat(U(-0.2,0.2)^3) (hovering_env.py:23-24).  Same 16-bit lattice as qso_random_init.
+ * out: init[26] (docking: chaser, target) or init[13] (hovering). */
+void FN(qso_ctor_init)(uint64_t seed, uint64_t gid, int kind, float *init)
+{
+    uint32_t w[4];
+    float u[8];
+    int i;
+    FN(qso_philox4x32_10)(seed, (STREAM_INIT << 48) | gid, 0, w);
+    for (i = 0; i < 4; ++i) { u[2 * i] = u16f(w[i] & 0xFFFFu); u[2 * i + 1] = u16f(w[i] >> 16); }
+    if (kind == 2) {
+        for (i = 0; i < 26; ++i) init[i] = 0;
+        init[0] = fmaf(fmaf(2.0f, u[0], -1.0f), 0.3f, 8.0f);
+        init[1] = fmaf(fmaf(2.0f, u[1], -1.0f), 0.3f, -50.0f);
+        init[2] = fmaf(fmaf(2.0f, u[2], -1.0f), 0.3f, 5.0f);
+        init[6] = 1.0f;
+        init[13] = 10.0f; init[14] = -50.0f; init[15] = 5.0f; init[19] = 1.0f;
+    } else {
+        float e0, e1, e2;
+        for (i = 0; i < 13; ++i) init[i] = 0;
+        init[0] = fmaf(2.0f, u[0], -1.0f);
+        init[1] = fmaf(2.0f, u[1], -1.0f);
+        init[2] = fmaf(fmaf(2.0f, u[2], -1.0f), 1.0f, 5.0f);
+        e0 = fmaf(2.0f, u[3], -1.0f) * 0.2f; e1 = fmaf(2.0f, u[4], -1.0f) * 0.2f; e2 = fmaf(2.0f, u[5], -1.0f) * 0.2f;
+        {
+            float cy = cosf(e2 * 0.5f), sy = sinf(e2 * 0.5f), cp = cosf(e1 * 0.5f), sp = sinf(e1 * 0.5f);
+            float cr = cosf(e0 * 0.5f), sr = sinf(e0 * 0.5f);
+            init[6] = cr * cp * cy - sr * sp * sy;
+            init[7] = sr * cp * cy - cr * sp * sy;
+            init[8] = sr * cp * sy + cr * sp * cy;
+            init[9] = cr * cp * sy + sr * sp * cy;
+        }
+    }
+}
+
 int FN(qso_real_size)(void) { return (int)sizeof(real); }

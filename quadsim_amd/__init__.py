@@ -7,12 +7,12 @@ library and a GPU.
 from . import _lib
 from ._lib import QuadsimError, build_library
 from .drone import Drone, controller, ctrl_batch, drone_step_batch, rel_obs_batch
-from .envs import DockingEnv, MovingDockingEnv, make, register_gym_ids
+from .envs import DockingEnv, HoveringEnv, ImitatingDockingEnv, MovingDockingEnv, make, register_gym_ids
 from .vec_env import C3_INIT_RANGE, VecDockingEnv, shard_range
 from . import distributed
 from .policy import MlpPolicy, rollout_with_policy
 
-__all__ = ["VecDockingEnv", "DockingEnv", "MovingDockingEnv", "Drone", "controller", "make", "register_gym_ids",
+__all__ = ["VecDockingEnv", "DockingEnv", "MovingDockingEnv", "ImitatingDockingEnv", "HoveringEnv", "Drone", "controller", "make", "register_gym_ids",
            "shard_range", "build_library", "QuadsimError", "C3_INIT_RANGE", "drone_step_batch", "ctrl_batch",
            "rel_obs_batch", "_lib", "distributed", "MlpPolicy", "rollout_with_policy"]
 

@@ -15,7 +15,7 @@ SOURCES = [os.path.join(CSRC, "quadsim_hip.hip")]
 HEADERS = [os.path.join(CSRC, "quadsim_device.hpp"), os.path.join(HERE, "..", "include", "quadsim.h")]
 
 QS_OK = 0
-KIND_V0, KIND_V2 = 0, 1
+KIND_V0, KIND_V2, KIND_V1, KIND_HOVER = 0, 1, 2, 3
 INTEG_FROZEN, INTEG_RK4 = 0, 1
 IO_DEVICE, IO_HOST = 0, 1
 RANDOMISE_NONE, RANDOMISE_INIT, RANDOMISE_PARAMS = 0, 1, 2
@@ -24,7 +24,7 @@ FLAG_DOCKED, FLAG_OVERLIMIT, FLAG_OVERTIME, FLAG_CHASER_LIMITED, FLAG_TARGET_LIM
 EXPORTS = [
     "qs_config_default", "qs_version", "qs_last_error", "qs_create", "qs_destroy", "qs_reset", "qs_step",
     "qs_rollout", "qs_rollout_stepwise", "qs_fill_random_actions", "qs_get_state", "qs_set_state", "qs_set_params", "qs_get_params",
-    "qs_get_step_counter", "qs_set_step_counter", "qs_set_stream", "qs_sync", "qs_timer_start", "qs_timer_stop",
+    "qs_set_init_state", "qs_get_init_state", "qs_obs_dim", "qs_get_step_counter", "qs_set_step_counter", "qs_set_stream", "qs_sync", "qs_timer_start", "qs_timer_stop",
     "qs_drone_step", "qs_ctrl", "qs_rel_obs",
 ]
 
@@ -99,6 +99,9 @@ def load():
         "qs_set_state": [vp] + [vp] * 6,
         "qs_set_params": [vp, vp, vp],
         "qs_get_params": [vp, vp, vp],
+        "qs_set_init_state": [vp, vp, vp],
+        "qs_get_init_state": [vp, vp, vp],
+        "qs_obs_dim": [vp, C.POINTER(i32)],
         "qs_get_step_counter": [vp, C.POINTER(u64)],
         "qs_set_step_counter": [vp, u64],
         "qs_set_stream": [vp, vp, i32],

@@ -43,7 +43,7 @@ struct Par {
 
 // env-kind constants, uniform over the launch (SGPRs)
 struct EnvConst {
-    int kind;      // 0 docking-v0, 1 docking-v2
+    int kind;      // target controller: 0 controller.PID (docking-v0/v1), 1 vel_controller (docking-v2)
     float dt;
     float rmax;    // 3 (docking_env.py:141) / 10 (moving_docking_env.py:148)
     float vdes_x;  // 0 / 0.2 (moving_docking_env.py:62)
@@ -568,6 +568,34 @@ __device__ __forceinline__ void env_reset(Env &e, const float ic[13], const floa
     e.ls = 0.0f;
     e.t = 0.0f;
     rel_obs<TARGET_LEVEL>(e.sc, e.st, obs);
+}
+
+// HoveringEnv.step, gym-docking/gym_docking/envs/hovering_env.py:47-78: one drone, action in [0,1]^4
+// scaled by action_max = m g (:42,:51), reward :62-76, done :68; state_des = hover at (0,0,5), level (:31-35).
+template <int INTEG>
+__device__ __forceinline__ void hover_step(float s[13], float u_prev[4], const float a[4], const Par &P, float dt,
+                                           float &reward, unsigned &flags)
+{
+    float amax = P.m * kG;
+    float f0 = amax * a[0], f1 = amax * a[1], f2 = amax * a[2], f3 = amax * a[3];
+    float u[4];
+    u[0] = (f0 + f1) + (f2 + f3);
+    u[1] = kL * (f1 - f3);
+    u[2] = kL * (f2 - f0);
+    u[3] = kLambda * ((f0 - f1) + (f2 - f3));
+    bool lim = drone_step<INTEG>(s, u_prev, u, P, dt);        // :52
+    float pe0 = -s[0], pe1 = -s[1], pe2 = 5.0f - s[2];        // :57
+    float r, p, y;
+    quat2euler(s + 6, r, p, y);                               // :59 (quat2euler of the level state_des is 0,0,0)
+    float npe = q_sqrt(pe0 * pe0 + pe1 * pe1 + pe2 * pe2);
+    float nve = q_sqrt(s[3] * s[3] + s[4] * s[4] + s[5] * s[5]);
+    float nae = q_sqrt(r * r + p * p + y * y);
+    float nwe = q_sqrt(s[10] * s[10] + s[11] * s[11] + s[12] * s[12]);
+    bool inside = (npe < 0.1f) && (nve < 0.1f);               // :63
+    bool done = (q_sqrt(s[0] * s[0] + s[1] * s[1] + s[2] * s[2]) > 100.0f) || (nve > 100.0f);   // :68
+    float rr = (inside ? 1.0f : 0.0f) + 0.1f - 0.01f * npe - 0.001f * nve - 0.01f * nae - 0.001f * nwe;  // :71-74
+    reward = done ? -0.1f : rr;                               // :76
+    flags = (inside ? FLAG_DOCKED : 0u) | (done ? FLAG_OVERLIMIT : 0u) | (lim ? FLAG_CLIM : 0u);
 }
 
 }  // namespace qs

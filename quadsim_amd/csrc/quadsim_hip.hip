@@ -46,6 +46,7 @@ struct StepArgs {
     int auto_reset;
     int randomise;
     float nominal_obs[12]; // state2rel of the nominal reset states (what a non-randomised reset returns)
+    const float *init;     // stored per-env initial states: [N][26] (docking: chaser, target) / [N][13] (hovering)
 };
 
 __device__ __forceinline__ void load_env(const float *__restrict__ st, int64_t tile, int lane, Env &e)
@@ -124,12 +125,19 @@ __device__ __forceinline__ void step_and_maybe_reset(Env &e, Par &P, const float
             e.t = 0.0f;
 #pragma unroll
             for (int i = 0; i < 12; ++i) obs[i] = A.nominal_obs[i];
+        } else if (RMODE == 3) {
+            // stored per-env initial state (docking-v1; script-set chaser_ini_state)
+            float ic[13], it[13];
+            const float *src = A.init + env * 26;
+#pragma unroll
+            for (int i = 0; i < 13; ++i) { ic[i] = src[i]; it[i] = src[13 + i]; }
+            env_reset<false>(e, ic, it, obs);
         } else {
             float ic[13], it[13];
             Par Pn;
-            random_init<RMODE >= 2>(A.rc, STREAM_AUTORESET, A.gid0 + (uint64_t)env, k + 1, ic, it, Pn);
-            if (PARAMS && RMODE >= 2) P = Pn;
-            env_reset<true>(e, ic, it, obs);   // reset states always have a level target
+            random_init<RMODE == 2>(A.rc, STREAM_AUTORESET, A.gid0 + (uint64_t)env, k + 1, ic, it, Pn);
+            if (PARAMS && RMODE == 2) P = Pn;
+            env_reset<true>(e, ic, it, obs);   // randomised reset states always have a level target
         }
     }
 }
@@ -170,7 +178,101 @@ __global__ __launch_bounds__(kBlock) void k_env(StepArgs A)
         if (A.flags) A.flags[o] = (uint8_t)flags;
     }
     store_env(A.st, tile, lane, e);
-    if (PARAMS && RMODE >= 2) store_par(A.par, tile, lane, P);
+    if (PARAMS && RMODE == 2) store_par(A.par, tile, lane, P);
+}
+
+// hovering-v0 (HoveringEnv.step, hovering_env.py:47-78): T fused steps, one drone per lane.  Uses rows F_SC..
+// (state) and F_UC.. (last limited control) of the tile; obs [T,N,13] = state after the step (or the stored
+// ini_state after an auto-reset, hovering_env.py:80-82).
+template <int INTEG, bool PARAMS>
+__global__ __launch_bounds__(kBlock) void k_hover(StepArgs A)
+{
+    const int lane = threadIdx.x & (kTile - 1);
+    const int64_t tile = (int64_t)blockIdx.x * (kBlock / kTile) + (threadIdx.x >> 6);
+    const int64_t env = tile * kTile + lane;
+    if (env >= A.n) return;
+    float *b = A.st + tile * (int64_t)(kRecWords * kTile) + lane;
+    float s[13], up[4];
+#pragma unroll
+    for (int i = 0; i < 13; ++i) s[i] = b[(F_SC + i) * kTile];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) up[i] = b[(F_UC + i) * kTile];
+    Par P = A.par_nom;
+    if (PARAMS) P = load_par(A.par, tile, lane);
+#pragma clang loop unroll(disable)
+    for (int64_t t = 0; t < A.T; ++t) {
+        const int64_t o = t * A.n + env;
+        float a[4];
+        if (A.actions) {
+            const float4 av = reinterpret_cast<const float4 *>(A.actions)[o];
+            a[0] = av.x; a[1] = av.y; a[2] = av.z; a[3] = av.w;
+        } else {
+            random_action(A.rc.seed, A.gid0 + (uint64_t)env, A.step_idx + (uint64_t)t, a);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = 0.5f * a[i] + 0.5f;    // hovering actions live in [0,1]
+        }
+        float reward;
+        unsigned flags;
+        hover_step<INTEG>(s, up, a, P, A.C.dt, reward, flags);
+        const bool done = (flags & FLAG_OVERLIMIT) != 0;
+        if (done && A.auto_reset) {
+            if (A.term_obs) for (int i = 0; i < 13; ++i) A.term_obs[env * 13 + i] = s[i];
+            const float *src = A.init + env * 13;
+#pragma unroll
+            for (int i = 0; i < 13; ++i) s[i] = src[i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) up[i] = 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 13; ++i) A.obs[o * 13 + i] = s[i];
+        A.reward[o] = reward;
+        A.done[o] = done ? 1 : 0;
+        if (A.flags) A.flags[o] = (uint8_t)flags;
+    }
+#pragma unroll
+    for (int i = 0; i < 13; ++i) b[(F_SC + i) * kTile] = s[i];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) b[(F_UC + i) * kTile] = up[i];
+}
+
+// construction-time jitter of docking-v1 (imitating_docking_env.py:34: chaser pos += U(-0.3,0.3)^3) and
+// hovering-v0 (hovering_env.py:23-24: pos = (0,0,5)+U(-1,1)^3, att = euler2quat(U(-0.2,0.2)^3)), drawn from
+// the rocRAND INIT stream (ctr 0) instead of numpy's global RNG; same 16-bit lattice as random_init.
+__global__ __launch_bounds__(kBlock) void k_ctor_init(float *init, int64_t n, int hover, uint64_t seed, uint64_t gid0)
+{
+    const int64_t env = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (env >= n) return;
+    uint4 w = philox_block(seed, 3ull, gid0 + (uint64_t)env, 0);
+    if (!hover) {
+        float *d = init + env * 26;
+        for (int i = 0; i < 26; ++i) d[i] = 0.0f;
+        d[0] = __fmaf_rn(sym(u16lo(w.x)), 0.3f, 8.0f);
+        d[1] = __fmaf_rn(sym(u16hi(w.x)), 0.3f, -50.0f);
+        d[2] = __fmaf_rn(sym(u16lo(w.y)), 0.3f, 5.0f);
+        d[6] = 1.0f;
+        d[13] = 10.0f; d[14] = -50.0f; d[15] = 5.0f; d[19] = 1.0f;
+    } else {
+        float *d = init + env * 13;
+        for (int i = 0; i < 13; ++i) d[i] = 0.0f;
+        d[0] = sym(u16lo(w.x));
+        d[1] = sym(u16hi(w.x));
+        d[2] = __fmaf_rn(sym(u16lo(w.y)), 1.0f, 5.0f);
+        float e0 = sym(u16hi(w.y)) * 0.2f, e1 = sym(u16lo(w.z)) * 0.2f, e2 = sym(u16hi(w.z)) * 0.2f;
+        float sr, cr, sp, cp, sy, cy;
+        q_sincos_small(0.5f * e0, sr, cr);
+        q_sincos_small(0.5f * e1, sp, cp);
+        q_sincos_small(0.5f * e2, sy, cy);
+        euler2quat_trig(sr, cr, sp, cp, sy, cy, d + 6);
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_fill_init_nominal(float *init, int64_t n)
+{
+    const int64_t env = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (env >= n) return;
+    float sc[13], st[13];
+    nominal_init(sc, st);
+    for (int i = 0; i < 13; ++i) { init[env * 26 + i] = sc[i]; init[env * 26 + 13 + i] = st[i]; }
 }
 
 // K2: masked reset (DockingEnv.reset, docking_env.py:233-244); init_all also rewrites q_des, like __init__
@@ -184,7 +286,10 @@ __global__ __launch_bounds__(kBlock) void k_reset(StepArgs A, const uint8_t *__r
     Env e;
     load_env(A.st, tile, lane, e);
     float ic[13], it[13], obs[12];
-    if (A.randomise) {
+    if (A.init) {
+        const float *src = A.init + env * 26;
+        for (int i = 0; i < 13; ++i) { ic[i] = src[i]; it[i] = src[13 + i]; }
+    } else if (A.randomise) {
         Par Pn;
         random_init<true>(A.rc, STREAM_RESET, A.gid0 + (uint64_t)env, A.step_idx, ic, it, Pn);
         if (A.randomise >= 2) store_par(A.par, tile, lane, Pn);
@@ -195,6 +300,20 @@ __global__ __launch_bounds__(kBlock) void k_reset(StepArgs A, const uint8_t *__r
     env_reset(e, ic, it, obs);
     store_env(A.st, tile, lane, e);
     if (A.obs) store_obs(A.obs, env, obs);
+}
+
+// HoveringEnv.reset (hovering_env.py:80-82): state <- stored ini_state, last control <- 0; obs = the state
+__global__ __launch_bounds__(kBlock) void k_hover_reset(StepArgs A, const uint8_t *__restrict__ mask)
+{
+    const int lane = threadIdx.x & (kTile - 1);
+    const int64_t tile = (int64_t)blockIdx.x * (kBlock / kTile) + (threadIdx.x >> 6);
+    const int64_t env = tile * kTile + lane;
+    if (env >= A.n) return;
+    if (mask && !mask[env]) return;
+    float *b = A.st + tile * (int64_t)(kRecWords * kTile) + lane;
+    const float *src = A.init + env * 13;
+    for (int i = 0; i < 13; ++i) { b[(F_SC + i) * kTile] = src[i]; if (A.obs) A.obs[env * 13 + i] = src[i]; }
+    for (int i = 0; i < 4; ++i) b[(F_UC + i) * kTile] = 0.0f;
 }
 
 __global__ void k_nominal_obs(float *out)
@@ -356,6 +475,8 @@ struct QsEnv {
     uint64_t step = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float nominal_obs[12] = {0};
+    float *init = nullptr;      // stored per-env initial states (docking-v1, hovering-v0, qs_set_init_state)
+    int obs_dim = 12;
     // staging for QS_IO_HOST
     void *stage = nullptr;
     size_t stage_bytes = 0;
@@ -373,10 +494,11 @@ StepArgs make_args(const QsEnv *e)
     A.T = 1;
     A.step_idx = e->step;
     A.gid0 = e->cfg.env_id_offset;
-    A.C.kind = e->cfg.kind;
+    A.C.kind = e->cfg.kind == QS_KIND_DOCKING_V2 ? 1 : 0;
     A.C.dt = e->cfg.dt;
-    A.C.rmax = e->cfg.kind == QS_KIND_DOCKING_V0 ? 3.0f : 10.0f;
-    A.C.vdes_x = e->cfg.kind == QS_KIND_DOCKING_V0 ? 0.0f : 0.2f;
+    A.C.rmax = e->cfg.kind == QS_KIND_DOCKING_V2 ? 10.0f : 3.0f;
+    A.C.vdes_x = e->cfg.kind == QS_KIND_DOCKING_V2 ? 0.2f : 0.0f;
+    A.init = e->init;
     A.rc.seed = e->cfg.seed;
     for (int i = 0; i < 4; ++i) A.rc.rr[i] = e->cfg.init_range[i];
     A.rc.rr[4] = e->cfg.mass_scale[0]; A.rc.rr[5] = e->cfg.mass_scale[1];
@@ -420,7 +542,8 @@ void launch_one(unsigned grid, hipStream_t s, const StepArgs &A)
 template <int INTEG>
 void launch_integ(unsigned grid, hipStream_t s, const StepArgs &A, bool params, int rmode)
 {
-    if (rmode >= 2) launch_one<INTEG, true, 2>(grid, s, A);      // per-episode params imply per-env params
+    if (rmode == 3) { if (params) launch_one<INTEG, true, 3>(grid, s, A); else launch_one<INTEG, false, 3>(grid, s, A); }
+    else if (rmode == 2) launch_one<INTEG, true, 2>(grid, s, A);      // per-episode params imply per-env params
     else if (rmode == 1) { if (params) launch_one<INTEG, true, 1>(grid, s, A); else launch_one<INTEG, false, 1>(grid, s, A); }
     else { if (params) launch_one<INTEG, true, 0>(grid, s, A); else launch_one<INTEG, false, 0>(grid, s, A); }
 }
@@ -428,8 +551,18 @@ void launch_integ(unsigned grid, hipStream_t s, const StepArgs &A, bool params, 
 int launch_env(QsEnv *e, StepArgs &A)
 {
     const unsigned grid = grid_tiles(e->n);
-    if (e->cfg.integrator == QS_INTEG_FROZEN) launch_integ<0>(grid, e->stream, A, e->per_env_params, e->cfg.randomise);
-    else launch_integ<1>(grid, e->stream, A, e->per_env_params, e->cfg.randomise);
+    if (e->cfg.kind == QS_KIND_HOVERING_V0) {
+        const bool fr = e->cfg.integrator == QS_INTEG_FROZEN, pp = e->per_env_params;
+        if (fr && !pp) hipLaunchKernelGGL((k_hover<0, false>), dim3(grid), dim3(kBlock), 0, e->stream, A);
+        else if (fr) hipLaunchKernelGGL((k_hover<0, true>), dim3(grid), dim3(kBlock), 0, e->stream, A);
+        else if (!pp) hipLaunchKernelGGL((k_hover<1, false>), dim3(grid), dim3(kBlock), 0, e->stream, A);
+        else hipLaunchKernelGGL((k_hover<1, true>), dim3(grid), dim3(kBlock), 0, e->stream, A);
+        HIP_TRY(hipGetLastError());
+        return QS_OK;
+    }
+    const int rmode = e->init ? 3 : e->cfg.randomise;   // stored initial states take precedence over `randomise`
+    if (e->cfg.integrator == QS_INTEG_FROZEN) launch_integ<0>(grid, e->stream, A, e->per_env_params, rmode);
+    else launch_integ<1>(grid, e->stream, A, e->per_env_params, rmode);
     HIP_TRY(hipGetLastError());
     return QS_OK;
 }
@@ -446,6 +579,9 @@ int do_reset(QsEnv *e, const uint8_t *d_mask, float *d_obs, int init_all)
 {
     StepArgs A = make_args(e);
     A.obs = d_obs;
+    if (e->cfg.kind == QS_KIND_HOVERING_V0)
+        hipLaunchKernelGGL(k_hover_reset, dim3(grid_tiles(e->n)), dim3(kBlock), 0, e->stream, A, d_mask);
+    else
     hipLaunchKernelGGL(k_reset, dim3(grid_tiles(e->n)), dim3(kBlock), 0, e->stream, A, d_mask, init_all);
     HIP_TRY(hipGetLastError());
     return QS_OK;
@@ -495,7 +631,10 @@ int qs_create(const QsConfig *cfg, QsEnv **out)
         return fail(QS_ERR_INVALID, "qs_create: QsConfig size mismatch (got %d, want %zu)", cfg->struct_size, sizeof(QsConfig));
     if (cfg->num_envs < 1) return fail(QS_ERR_INVALID, "qs_create: num_envs must be >= 1");
     if (cfg->num_envs > ((int64_t)1 << 31)) return fail(QS_ERR_INVALID, "qs_create: num_envs too large");
-    if (cfg->kind != QS_KIND_DOCKING_V0 && cfg->kind != QS_KIND_DOCKING_V2) return fail(QS_ERR_INVALID, "qs_create: unknown env kind %d", cfg->kind);
+    if (cfg->kind < QS_KIND_DOCKING_V0 || cfg->kind > QS_KIND_HOVERING_V0) return fail(QS_ERR_INVALID, "qs_create: unknown env kind %d", cfg->kind);
+    if ((cfg->kind == QS_KIND_DOCKING_V1 || cfg->kind == QS_KIND_HOVERING_V0) && cfg->randomise == QS_RANDOMISE_INIT)
+        return fail(QS_ERR_INVALID, "qs_create: docking-v1 / hovering-v0 reset to their stored initial state; randomise must be 0");
+    if (cfg->kind == QS_KIND_HOVERING_V0 && cfg->randomise != 0) return fail(QS_ERR_INVALID, "qs_create: hovering-v0 has no randomised resets");
     if (cfg->integrator != QS_INTEG_FROZEN && cfg->integrator != QS_INTEG_RK4) return fail(QS_ERR_INVALID, "qs_create: unknown integrator %d", cfg->integrator);
     if (cfg->randomise < 0 || cfg->randomise > 2) return fail(QS_ERR_INVALID, "qs_create: randomise must be 0..2");
     if (cfg->io_space != QS_IO_DEVICE && cfg->io_space != QS_IO_HOST) return fail(QS_ERR_INVALID, "qs_create: bad io_space");
@@ -516,6 +655,7 @@ int qs_create(const QsConfig *cfg, QsEnv **out)
     e->n = cfg->num_envs;
     e->tiles = tiles_of(e->n);
     e->per_env_params = cfg->randomise >= QS_RANDOMISE_PARAMS;
+    e->obs_dim = cfg->kind == QS_KIND_HOVERING_V0 ? 13 : 12;
     int rc = QS_OK;
     auto body = [&]() -> int {
         if (cfg->external_stream) e->stream = (hipStream_t)cfg->stream;
@@ -536,10 +676,20 @@ int qs_create(const QsConfig *cfg, QsEnv **out)
         HIP_TRY(hipMemcpyAsync(e->nominal_obs, e->par + (size_t)e->tiles * kParWords * kTile, 12 * sizeof(float),
                                hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
-        // __init__: nominal states, q_des = identity; never randomised (randomisation starts at the first reset)
+        if (cfg->kind == QS_KIND_DOCKING_V1 || cfg->kind == QS_KIND_HOVERING_V0) {
+            const bool hover = cfg->kind == QS_KIND_HOVERING_V0;
+            HIP_TRY(hipMalloc((void **)&e->init, (size_t)e->n * (hover ? 13 : 26) * sizeof(float)));
+            hipLaunchKernelGGL(k_ctor_init, dim3(grid_flat(e->n)), dim3(kBlock), 0, e->stream, e->init, e->n, hover ? 1 : 0,
+                               cfg->seed, cfg->env_id_offset);
+            HIP_TRY(hipGetLastError());
+        }
+        // __init__: initial states (nominal / stored), q_des = identity; per-episode randomisation starts at the first reset
         StepArgs A = make_args(e);
         A.randomise = 0;
-        hipLaunchKernelGGL(k_reset, dim3(grid_tiles(e->n)), dim3(kBlock), 0, e->stream, A, (const uint8_t *)nullptr, 1);
+        if (cfg->kind == QS_KIND_HOVERING_V0)
+            hipLaunchKernelGGL(k_hover_reset, dim3(grid_tiles(e->n)), dim3(kBlock), 0, e->stream, A, (const uint8_t *)nullptr);
+        else
+            hipLaunchKernelGGL(k_reset, dim3(grid_tiles(e->n)), dim3(kBlock), 0, e->stream, A, (const uint8_t *)nullptr, 1);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(e->stream));
         return QS_OK;
@@ -557,6 +707,7 @@ int qs_destroy(QsEnv *e)
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->st) (void)hipFree(e->st);
     if (e->par) (void)hipFree(e->par);
+    if (e->init) (void)hipFree(e->init);
     if (e->stage) (void)hipFree(e->stage);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
@@ -618,16 +769,17 @@ int qs_reset(QsEnv *e, const uint8_t *mask, float *obs_out)
     CHECK_ENV(e);
     const int64_t n = e->n;
     if (e->cfg.io_space == QS_IO_DEVICE) return do_reset(e, mask, obs_out, 0);
-    int r = ensure_stage(e, (size_t)n * (12 * 4 + 1) + 1024);
+    const int64_t od = e->obs_dim;
+    int r = ensure_stage(e, (size_t)n * (od * 4 + 1) + 1024);
     if (r) return r;
     Stage S{(char *)e->stage};
-    float *d_obs = S.take<float>(n * 12);
+    float *d_obs = S.take<float>(n * od);
     uint8_t *d_mask = S.take<uint8_t>(n);
     if (mask) HIP_TRY(hipMemcpyAsync(d_mask, mask, n, hipMemcpyHostToDevice, e->stream));
-    if (obs_out && mask) HIP_TRY(hipMemcpyAsync(d_obs, obs_out, n * 12 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    if (obs_out && mask) HIP_TRY(hipMemcpyAsync(d_obs, obs_out, n * od * sizeof(float), hipMemcpyHostToDevice, e->stream));
     r = do_reset(e, mask ? d_mask : nullptr, d_obs, 0);
     if (r) return r;
-    if (obs_out) HIP_TRY(hipMemcpyAsync(obs_out, d_obs, n * 12 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+    if (obs_out) HIP_TRY(hipMemcpyAsync(obs_out, d_obs, n * od * sizeof(float), hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return QS_OK;
 }
@@ -644,23 +796,24 @@ int qs_step(QsEnv *e, const float *actions, float *obs, float *reward, uint8_t *
         r = launch_env(e, A);
         if (r) return r;
     } else {
-        r = ensure_stage(e, (size_t)n * (4 * 4 + 12 * 4 + 4 + 1 + 1 + 12 * 4) + 4096);
+        const int64_t od = e->obs_dim;
+        r = ensure_stage(e, (size_t)n * (4 * 4 + od * 4 + 4 + 1 + 1 + od * 4) + 4096);
         if (r) return r;
         Stage S{(char *)e->stage};
-        float *d_act = S.take<float>(n * 4), *d_obs = S.take<float>(n * 12), *d_rew = S.take<float>(n);
+        float *d_act = S.take<float>(n * 4), *d_obs = S.take<float>(n * od), *d_rew = S.take<float>(n);
         uint8_t *d_done = S.take<uint8_t>(n), *d_flags = S.take<uint8_t>(n);
-        float *d_term = S.take<float>(n * 12);
+        float *d_term = S.take<float>(n * od);
         HIP_TRY(hipMemcpyAsync(d_act, actions, n * 4 * sizeof(float), hipMemcpyHostToDevice, e->stream));
-        if (terminal_obs) HIP_TRY(hipMemcpyAsync(d_term, terminal_obs, n * 12 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        if (terminal_obs) HIP_TRY(hipMemcpyAsync(d_term, terminal_obs, n * od * sizeof(float), hipMemcpyHostToDevice, e->stream));
         A.actions = d_act; A.obs = d_obs; A.reward = d_rew; A.done = d_done; A.flags = d_flags;
         A.term_obs = terminal_obs ? d_term : nullptr;
         r = launch_env(e, A);
         if (r) return r;
-        HIP_TRY(hipMemcpyAsync(obs, d_obs, n * 12 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(obs, d_obs, n * od * sizeof(float), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipMemcpyAsync(reward, d_rew, n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipMemcpyAsync(done, d_done, n, hipMemcpyDeviceToHost, e->stream));
         if (flags) HIP_TRY(hipMemcpyAsync(flags, d_flags, n, hipMemcpyDeviceToHost, e->stream));
-        if (terminal_obs) HIP_TRY(hipMemcpyAsync(terminal_obs, d_term, n * 12 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        if (terminal_obs) HIP_TRY(hipMemcpyAsync(terminal_obs, d_term, n * od * sizeof(float), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
     }
     e->step += 1;
@@ -682,16 +835,17 @@ int qs_rollout(QsEnv *e, int64_t T, const float *actions, float *obs, float *rew
         r = launch_env(e, A);
         if (r) return r;
     } else {
-        r = ensure_stage(e, (size_t)tn * (4 * 4 + 12 * 4 + 4 + 1 + 1) + 4096);
+        const int64_t od = e->obs_dim;
+        r = ensure_stage(e, (size_t)tn * (4 * 4 + od * 4 + 4 + 1 + 1) + 4096);
         if (r) return r;
         Stage S{(char *)e->stage};
-        float *d_act = S.take<float>(tn * 4), *d_obs = S.take<float>(tn * 12), *d_rew = S.take<float>(tn);
+        float *d_act = S.take<float>(tn * 4), *d_obs = S.take<float>(tn * od), *d_rew = S.take<float>(tn);
         uint8_t *d_done = S.take<uint8_t>(tn), *d_flags = S.take<uint8_t>(tn);
         if (actions) HIP_TRY(hipMemcpyAsync(d_act, actions, tn * 4 * sizeof(float), hipMemcpyHostToDevice, e->stream));
         A.actions = actions ? d_act : nullptr; A.obs = d_obs; A.reward = d_rew; A.done = d_done; A.flags = d_flags;
         r = launch_env(e, A);
         if (r) return r;
-        HIP_TRY(hipMemcpyAsync(obs, d_obs, tn * 12 * sizeof(float), hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipMemcpyAsync(obs, d_obs, tn * od * sizeof(float), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipMemcpyAsync(reward, d_rew, tn * sizeof(float), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipMemcpyAsync(done, d_done, tn, hipMemcpyDeviceToHost, e->stream));
         if (flags) HIP_TRY(hipMemcpyAsync(flags, d_flags, tn, hipMemcpyDeviceToHost, e->stream));
@@ -712,7 +866,7 @@ int qs_rollout_stepwise(QsEnv *e, int64_t T, const float *actions, float *obs, f
     for (int64_t t = 0; t < T; ++t) {
         A.step_idx = e->step + (uint64_t)t;
         A.actions = actions + t * n * 4;
-        A.obs = obs + t * n * 12;
+        A.obs = obs + t * n * e->obs_dim;
         A.reward = reward + t * n;
         A.done = done + t * n;
         A.flags = flags ? flags + t * n : nullptr;
@@ -830,6 +984,56 @@ int qs_get_params(QsEnv *e, float *mass, float *inertia)
 {
     CHECK_ENV(e);
     return par_io(e, true, mass, inertia);
+}
+
+int qs_obs_dim(QsEnv *e, int32_t *dim)
+{
+    if (!e || !dim) return fail(QS_ERR_INVALID, "qs_obs_dim: null argument");
+    *dim = e->obs_dim;
+    return QS_OK;
+}
+
+static int init_io(QsEnv *e, bool to_user, float *chaser, float *target)
+{
+    const int64_t n = e->n;
+    const bool hover = e->cfg.kind == QS_KIND_HOVERING_V0;
+    const int64_t w = hover ? 13 : 26;
+    // the store is row-major [n][w]; user arrays are [n][13] each: strided 2-D copies
+    const hipMemcpyKind kd = e->cfg.io_space == QS_IO_HOST ? (to_user ? hipMemcpyDeviceToHost : hipMemcpyHostToDevice)
+                                                             : hipMemcpyDeviceToDevice;
+    if (chaser) {
+        if (to_user) HIP_TRY(hipMemcpy2DAsync(chaser, 52, e->init, w * 4, 52, n, kd, e->stream));
+        else HIP_TRY(hipMemcpy2DAsync(e->init, w * 4, chaser, 52, 52, n, kd, e->stream));
+    }
+    if (target && !hover) {
+        if (to_user) HIP_TRY(hipMemcpy2DAsync(target, 52, e->init + 13, w * 4, 52, n, kd, e->stream));
+        else HIP_TRY(hipMemcpy2DAsync(e->init + 13, w * 4, target, 52, 52, n, kd, e->stream));
+    }
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return QS_OK;
+}
+
+int qs_set_init_state(QsEnv *e, const float *chaser_init, const float *target_init)
+{
+    CHECK_ENV(e);
+    if (!chaser_init) return fail(QS_ERR_INVALID, "qs_set_init_state: chaser_init is required");
+    const bool hover = e->cfg.kind == QS_KIND_HOVERING_V0;
+    if (!e->init) {
+        // first use on a docking-v0/v2 handle: start from the nominal pair for every env
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipMalloc((void **)&e->init, (size_t)e->n * 26 * sizeof(float)));
+        hipLaunchKernelGGL(k_fill_init_nominal, dim3(grid_flat(e->n)), dim3(kBlock), 0, e->stream, e->init, e->n);
+        HIP_TRY(hipGetLastError());
+    }
+    (void)hover;
+    return init_io(e, false, (float *)chaser_init, (float *)target_init);
+}
+
+int qs_get_init_state(QsEnv *e, float *chaser_init, float *target_init)
+{
+    CHECK_ENV(e);
+    if (!e->init) return fail(QS_ERR_INVALID, "qs_get_init_state: this handle resets to the nominal / randomised state (no stored initial states)");
+    return init_io(e, true, chaser_init, target_init);
 }
 
 // ---- layer 1 ---------------------------------------------------------------------------------

@@ -40,3 +40,11 @@ def docking_spaces():
     action_space = Box(low=np.array([-1.0, -1.0, -1.0, -1.0]), high=np.array([1.0, 1.0, 1.0, 1.0]), dtype=np.float32)
     observation_space = Box(low=obs_low, high=obs_high, dtype=np.float32)
     return observation_space, action_space
+
+
+def hovering_spaces():
+    """(observation_space, action_space) of hovering-v0: hovering_env.py:37-41 with Drone.state_lim_* (quadrotor.py:35-39)"""
+    tp = 10 * 2 * np.pi
+    low = np.array([-100, -100, 0, -100, -100, -100, -100, -100, -100, -100, -tp, -tp, -tp])
+    high = np.array([100, 100, 100, 100, 100, 100, 100, 100, 100, 100, tp, tp, tp])
+    return Box(low=low, high=high, dtype=np.float32), Box(low=np.zeros(4), high=np.ones(4), dtype=np.float32)

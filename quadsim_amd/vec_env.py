@@ -14,10 +14,11 @@ import ctypes as C
 import numpy as np
 
 from . import _lib
-from .spaces import Box, docking_spaces
+from .spaces import Box, docking_spaces, hovering_spaces
 
-_KINDS = {"docking-v0": _lib.KIND_V0, "docking-v2": _lib.KIND_V2,
-          "gym_docking:docking-v0": _lib.KIND_V0, "gym_docking:docking-v2": _lib.KIND_V2}
+_KINDS = {"docking-v0": _lib.KIND_V0, "docking-v2": _lib.KIND_V2, "docking-v1": _lib.KIND_V1,
+          "hovering-v0": _lib.KIND_HOVER}
+_KINDS.update({"gym_docking:" + k: v for k, v in list(_KINDS.items())})
 _INTEG = {"frozen": _lib.INTEG_FROZEN, "rk4": _lib.INTEG_RK4}
 
 # chaser initial-state jitter of BASELINE config 3: the ranges commented out at docking_env.py:34-37
@@ -61,7 +62,9 @@ class VecDockingEnv:
         self.num_envs = int(num_envs)
         self.backend = backend
         self.device_index = int(device)
-        self.observation_space, self.action_space = docking_spaces()
+        self.obs_dim = 13 if self.kind == _lib.KIND_HOVER else 12
+        self.observation_space, self.action_space = (hovering_spaces() if self.kind == _lib.KIND_HOVER
+                                                     else docking_spaces())
         self._lib = _lib.load()
         torch = _torch()
         if not torch.cuda.is_available():
@@ -93,11 +96,11 @@ class VecDockingEnv:
         _lib.check(self._lib.qs_create(C.byref(cfg), C.byref(self._h)), "qs_create")
         n = self.num_envs
         kw = dict(device=self.device)
-        self._obs = torch.empty((n, 12), dtype=torch.float32, **kw)
+        self._obs = torch.empty((n, self.obs_dim), dtype=torch.float32, **kw)
         self._rew = torch.empty((n,), dtype=torch.float32, **kw)
         self._done = torch.empty((n,), dtype=torch.uint8, **kw)
         self._flags = torch.empty((n,), dtype=torch.uint8, **kw)
-        self._term = torch.zeros((n, 12), dtype=torch.float32, **kw)
+        self._term = torch.zeros((n, self.obs_dim), dtype=torch.float32, **kw)
         self._actions = None
         self.auto_reset = bool(auto_reset)
         # attribute surface the reference scripts poke (run_trained_docking_ppo2.py:45)
@@ -179,7 +182,7 @@ class VecDockingEnv:
         if out is not None:
             obs, rew, done, flags = out
         else:
-            obs = torch.empty((T, n, 12), dtype=torch.float32, device=self.device)
+            obs = torch.empty((T, n, self.obs_dim), dtype=torch.float32, device=self.device)
             rew = torch.empty((T, n), dtype=torch.float32, device=self.device)
             done = torch.empty((T, n), dtype=torch.uint8, device=self.device)
             flags = torch.empty((T, n), dtype=torch.uint8, device=self.device) if want_flags else None
@@ -253,6 +256,21 @@ class VecDockingEnv:
         _lib.check(self._lib.qs_set_state(self._h, *ptrs), "qs_set_state")
         self.sync()
 
+    def set_init_state(self, chaser_init, target_init=None):
+        """per-env initial states reset() returns to (env.chaser_ini_state / target_ini_state; HoveringEnv.ini_state)"""
+        n = self.num_envs
+        c = self._as_device(chaser_init, (n, 13))
+        t = self._as_device(target_init, (n, 13)) if target_init is not None else None
+        _lib.check(self._lib.qs_set_init_state(self._h, self._ptr(c), self._ptr(t)), "qs_set_init_state")
+
+    def get_init_state(self):
+        torch = _torch()
+        n = self.num_envs
+        c = torch.empty((n, 13), dtype=torch.float32, device=self.device)
+        t = torch.empty((n, 13), dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.qs_get_init_state(self._h, self._ptr(c), self._ptr(t)), "qs_get_init_state")
+        return c.cpu().numpy(), (None if self.kind == _lib.KIND_HOVER else t.cpu().numpy())
+
     def set_params(self, mass=None, inertia=None):
         n = self.num_envs
         m = self._as_device(mass, (n,)) if mass is not None else None
@@ -304,8 +322,11 @@ class InfoView:
         if self._state is None:
             self._state = self._env.get_state()
         f = int(self._flags[i])
-        info = {"chaser": self._state["chaser"][i], "target": self._state["target"][i],
-                "flag_docking": bool(f & _lib.FLAG_DOCKED), "done_overlimit": bool(f & _lib.FLAG_OVERLIMIT)}
+        if self._env.kind == _lib.KIND_HOVER:
+            info = {}                                         # hovering_env.py:78 returns an empty info
+        else:
+            info = {"chaser": self._state["chaser"][i], "target": self._state["target"][i],
+                    "flag_docking": bool(f & _lib.FLAG_DOCKED), "done_overlimit": bool(f & _lib.FLAG_OVERLIMIT)}
         if self._done[i] and self._env.auto_reset:
             info["terminal_observation"] = self._term[i].copy()
         return info

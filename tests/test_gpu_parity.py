@@ -423,3 +423,138 @@ def test_policy_in_the_loop_reaches_docked_state(qa):
     assert abs(float(R[:, 0].sum()) - float(g["reward"].sum())) < 5e-3
     assert abs(int((F[:, 0] & 1).sum()) - 183) <= 3
     assert bool(D[599, 0]) and not D[:599, 0].any() and (F[599, 0] & 4)
+
+
+# ---------------------------------------------------------------- section 8f-2: docking-v1, hovering-v0
+def test_g8_docking_v1_golden(qa):
+    """docking-v1: single-step parity on every recorded step + the stored-initial-state reset (VecEnv auto-reset
+    returns the reference's reset() observation of the construction-time jittered start)"""
+    g = load_golden("g8_traj_v1")
+    for j in range(3):
+        key = "e%d_" % j
+        _golden_single_steps(qa, g, "docking-v1", 0, prefix=key)
+        # closed loop, N = 4 identical envs with the reference's drawn chaser_ini_state injected
+        env = qa.VecDockingEnv("docking-v1", num_envs=4)
+        env.set_init_state(np.tile(g[key + "chaser_ini_state"], (4, 1)), np.tile(g[key + "target_ini_state"], (4, 1)))
+        obs = env.reset().cpu().numpy()
+        np.testing.assert_allclose(obs[0], g[key + "first_obs"], **OBS_TOL)
+        n_done = 0
+        for t in range(300):
+            o, r, d, info = env.step(np.tile(g[key + "actions"][t], (4, 1)))
+            o, d = o.cpu().numpy(), d.cpu().numpy()
+            assert bool(d[0]) == bool(g[key + "done"][t]), t
+            ref = g[key + "reset_obs"][t] if d[0] else g[key + "obs"][t]
+            np.testing.assert_allclose(o[0], ref, rtol=1e-3, atol=1e-3)
+            if d[0]:
+                np.testing.assert_allclose(o[0], g[key + "reset_obs"][t], **OBS_TOL)     # reset obs is exact-ish
+                np.testing.assert_allclose(info[0]["terminal_observation"], g[key + "obs"][t], rtol=1e-3, atol=1e-3)
+                n_done += 1
+        assert n_done >= 3
+        env.close()
+
+
+def test_docking_v1_ctor_jitter_matches_oracle(qa, oracle64):
+    env = qa.VecDockingEnv("docking-v1", num_envs=300, seed=42, env_id_offset=7)
+    c, t = env.get_init_state()
+    st = env.get_state()
+    for i in (0, 1, 64, 299):
+        ref = oracle64.ctor_init(42, 7 + i, 2)
+        np.testing.assert_array_equal(c[i], ref[:13]); np.testing.assert_array_equal(t[i], ref[13:])
+        np.testing.assert_array_equal(st["chaser"][i], ref[:13])
+    assert np.all(np.abs(c[:, 0:3] - [8, -50, 5]) <= 0.3 + 1e-6) and c[:, 0].std() > 0.1
+    env.close()
+
+
+def test_g9_hovering_golden(qa, oracle64):
+    g = load_golden("g9_hovering")
+    for key, extra in (("e0_", True), ("e1_", True), ("e2_", True), ("c_", False)):
+        sb, ub = g[key + "state_before"], g[key + "u_before"]
+        n = len(sb)
+        env = qa.VecDockingEnv("hovering-v0", num_envs=n, auto_reset=False)
+        env.set_state(chaser=sb, u_prev=np.concatenate([ub, np.zeros((n, 4))], axis=1))
+        obs, rew, done, infos = env.step(g[key + "actions"])
+        obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+        st = env.get_state()
+        env.close()
+        np.testing.assert_allclose(obs, g[key + "state_after"], **STATE_TOL)
+        np.testing.assert_allclose(st["u_prev"][:, :4], g[key + "u_after"], rtol=1e-5, atol=1e-5)
+        safe = np.ones(n, bool) if extra else g["c_margin"] > 1e-4
+        assert np.array_equal(done[safe], g[key + "done"][safe].astype(bool))
+        assert np.all(np.abs(rew[safe] - g[key + "reward"][safe]) <= 2e-5)
+    assert (g["c_reward"] > 1.0).sum() > 30          # the +1 bonus branch is in the fixture
+    # closed loop with auto-reset to the reference's drawn ini_state: the climb-away episode reaches done
+    key = "e2_"
+    env = qa.VecDockingEnv("hovering-v0", num_envs=2)
+    env.set_init_state(np.tile(g[key + "ini_state"], (2, 1)))
+    np.testing.assert_allclose(env.reset().cpu().numpy()[0], g[key + "ini_state"], rtol=1e-7)
+    nd = 0
+    for t in range(400):
+        o, r, d, info = env.step(np.tile(g[key + "actions"][t], (2, 1)))
+        assert bool(d[0]) == bool(g[key + "done"][t]), t
+        if d[0]:
+            np.testing.assert_allclose(o.cpu().numpy()[0], g[key + "ini_state"], rtol=1e-7)
+            np.testing.assert_allclose(info[0]["terminal_observation"], g[key + "state_after"][t], rtol=2e-3, atol=2e-3)
+            nd += 1
+        else:
+            np.testing.assert_allclose(o.cpu().numpy()[0], g[key + "state_after"][t], rtol=2e-3, atol=2e-3)
+    assert nd >= 2
+    env.close()
+
+
+def test_hovering_vec_vs_oracle_and_rollout(qa):
+    """4096 hovering envs, rocRAND construction jitter, 30 steps vs the f64 oracle step by step; fused roll-out == steps"""
+    n, seed = 4096, 9
+    env = qa.VecDockingEnv("hovering-v0", num_envs=n, seed=seed)
+    orc = Oracle("f64")
+    init, _ = env.get_init_state()
+    for i in (0, 77, 4095):
+        np.testing.assert_allclose(init[i], orc.ctor_init(seed, i, 3), atol=2e-7)
+    env.reset()
+    rs = np.random.RandomState(3)
+    big = np.zeros((n, 13), np.float32); big[:] = init; big[::5, 0:3] += 99.0      # a fifth start near the |pos| > 100 limit
+    env.set_state(chaser=big)
+    par = tile_par(n)
+    nd = 0
+    for k in range(30):
+        st = env.get_state()
+        s17 = np.concatenate([st["chaser"], st["u_prev"][:, :4]], axis=1).astype(np.float64)
+        a = rs.uniform(0, 1, (n, 4)).astype(np.float32)
+        obs, rew, done, infos = env.step(a)
+        o, r, d, f, term = orc.hover_vec_step(s17, par, a, init.astype(np.float64), want_term=True)
+        pre_pos = np.linalg.norm(np.where(d[:, None].astype(bool), term[:, 0:3], o[:, 0:3]), axis=1)
+        safe = np.abs(pre_pos - 100.0) > 1e-3
+        assert np.array_equal(done.cpu().numpy()[safe], d[safe].astype(bool))
+        np.testing.assert_allclose(obs.cpu().numpy()[safe], o[safe], **STATE_TOL)
+        np.testing.assert_allclose(rew.cpu().numpy()[safe], r[safe], rtol=0, atol=2e-5)
+        nd += int(d.sum())
+    assert nd > 100
+    e1 = qa.VecDockingEnv("hovering-v0", num_envs=500, seed=1); e2 = qa.VecDockingEnv("hovering-v0", num_envs=500, seed=1)
+    e1.reset(); e2.reset()
+    acts = e1.random_actions(20, step0=0) * 0.5 + 0.5
+    O, R, D, F = e1.rollout(acts)
+    for t in range(20):
+        o, r, d, _ = e2.step(acts[t])
+        assert np.array_equal(o.cpu().numpy(), O[t].cpu().numpy()) and np.array_equal(r.cpu().numpy(), R[t].cpu().numpy())
+    for e in (env, e1, e2):
+        e.close()
+
+
+def test_single_env_shims_v1_and_hovering(qa):
+    g = load_golden("g9_hovering")
+    env = qa.make("hovering-v0")
+    env.ini_state = g["e0_ini_state"].copy()
+    s = env.reset()
+    np.testing.assert_allclose(s, g["e0_ini_state"], rtol=1e-7)
+    for t in range(100):
+        s, r, d, info = env.step(g["e0_actions"][t])
+        np.testing.assert_allclose(s, g["e0_state_after"][t], rtol=1e-3, atol=1e-3)
+        assert info == {} and abs(r - g["e0_reward"][t]) < 1e-3
+    env.close()
+    g8 = load_golden("g8_traj_v1")
+    e1 = qa.make("docking-v1", seed=3)
+    assert np.max(np.abs(e1.chaser_ini_state[0:3] - [8, -50, 5])) <= 0.3 + 1e-6
+    e1.chaser_ini_state = g8["e0_chaser_ini_state"].copy()
+    np.testing.assert_allclose(e1.reset(), g8["e0_first_obs"], **OBS_TOL)
+    o, r, d, info = e1.step(g8["e0_actions"][0])
+    np.testing.assert_allclose(o, g8["e0_obs"][0], **OBS_TOL)
+    e1.close()

@@ -167,3 +167,67 @@ def test_random_init_ranges(oracle64):
     U = np.array(U)
     assert U.min() > 0 and U.max() < 1 and abs(U.mean() - 0.5) < 0.02 and abs(U.var() - 1 / 12) < 0.01
     assert np.all(U * 65536 - 0.5 == np.round(U * 65536 - 0.5))        # 16-bit lattice (h + 1/2) / 65536
+
+
+# ---------------------------------------------------------------- section 8f-2: docking-v1, hovering-v0
+def test_g8_docking_v1(oracle64):
+    """docking-v1 == docking-v0 whose reset returns to the construction-time jittered chaser state"""
+    g = load_golden("g8_traj_v1")
+    for j in range(3):
+        key = "e%d_" % j
+        _check_single_steps(oracle64, g, 0, prefix=key)
+        init = np.concatenate([g[key + "chaser_ini_state"], g[key + "target_ini_state"]])[None]
+        rec = oracle64.env_init(1)
+        rec[0, 0:13] = init[0, :13]
+        np.testing.assert_allclose(oracle64.rel_obs(init[0, :13], init[0, 13:]), g[key + "first_obs"], **TOL)
+        par = np.array([PAR_NOMINAL], np.float64)
+        for t in range(len(g[key + "actions"])):
+            np.testing.assert_allclose(rec[0], g[key + "rec_before"][t], rtol=1e-9, atol=1e-9)
+            obs, rew, done, flags, term = oracle64.vec_step_stored_init(rec, par, g[key + "actions"][t][None], init,
+                                                                        want_term=True)
+            assert bool(done[0]) == bool(g[key + "done"][t])
+            ref = g[key + "reset_obs"][t] if done[0] else g[key + "obs"][t]
+            np.testing.assert_allclose(obs[0], ref, rtol=1e-9, atol=1e-9)
+        assert g[key + "done"].sum() >= 10
+
+
+def test_g9_hovering(oracle64):
+    g = load_golden("g9_hovering")
+    for j in range(3):
+        key = "e%d_" % j
+        sb, ub = g[key + "state_before"], g[key + "u_before"]
+        for t in range(len(sb)):
+            s, up, rew, done, flags = oracle64.hover_step(sb[t], ub[t], g[key + "actions"][t])
+            np.testing.assert_allclose(s, g[key + "state_after"][t], **TOL)
+            np.testing.assert_allclose(up, g[key + "u_after"][t], **TOL)
+            assert abs(rew - g[key + "reward"][t]) < 1e-12 and done == bool(g[key + "done"][t])
+        # closed loop with auto-reset to ini_state
+        st = np.zeros((1, 17)); st[0, :13] = g[key + "ini_state"]
+        par = np.array([PAR_NOMINAL], np.float64)
+        for t in range(len(sb)):
+            np.testing.assert_allclose(st[0, :13], sb[t], rtol=1e-9, atol=1e-9)
+            obs, rew, done, flags, term = oracle64.hover_vec_step(st, par, g[key + "actions"][t][None],
+                                                                  g[key + "ini_state"][None], want_term=True)
+            assert bool(done[0]) == bool(g[key + "done"][t])
+            if done[0]:
+                np.testing.assert_allclose(term[0], g[key + "state_after"][t], rtol=1e-9, atol=1e-9)
+                np.testing.assert_allclose(obs[0], g[key + "ini_state"], rtol=0, atol=0)
+    assert g["e2_done"].sum() >= 5
+    # crafted cases around the +1 bonus ball
+    n_bonus = 0
+    for i in range(len(g["c_state_before"])):
+        s, up, rew, done, flags = oracle64.hover_step(g["c_state_before"][i], g["c_u_before"][i], g["c_actions"][i])
+        np.testing.assert_allclose(s, g["c_state_after"][i], **TOL)
+        assert abs(rew - g["c_reward"][i]) < 1e-12
+        n_bonus += flags & 1
+    assert n_bonus == int((g["c_reward"] > 1.0).sum()) and n_bonus > 30
+
+
+def test_ctor_init_ranges(oracle64):
+    for gid in range(200):
+        d = oracle64.ctor_init(5, gid, 2)
+        assert np.all(np.abs(d[0:3] - [8, -50, 5]) <= 0.3 + 1e-6) and d[6] == 1 and np.all(d[3:6] == 0)
+        np.testing.assert_array_equal(d[13:], [10, -50, 5, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0])
+        h = oracle64.ctor_init(5, gid, 3)
+        assert np.all(np.abs(h[0:3] - [0, 0, 5]) <= 1 + 1e-6) and abs(np.linalg.norm(h[6:10]) - 1) < 1e-6
+        assert np.all(h[10:] == 0) and np.all(h[3:6] == 0)
