@@ -183,6 +183,17 @@ int qs_sync(QsEnv *env);
 int qs_timer_start(QsEnv *env);
 int qs_timer_stop(QsEnv *env, float *elapsed_ms); /* synchronises on the stop event */
 
+/* ---- roll-out post-processing: the steps either side of env.step in the trainer's Runner --------- */
+
+/* GAE(lambda) reverse scan, rl_baselines/ppo2/ppo2.py:507-520.  rewards, values [T,n] float32; dones [T,n] u8 =
+ * mb_dones (the done flag BEFORE step t, :474); last_values [n] = model.value(last obs); last_dones [n] = self.dones
+ * after the last step.  Out: advs [T,n] (mb_advs), returns [T,n] (mb_returns = advs + values).  Device buffers. */
+int qs_gae(QsEnv *env, int64_t T, int64_t n, const float *rewards, const float *values, const uint8_t *dones,
+           const float *last_values, const uint8_t *last_dones, float gamma, float lam, float *advs, float *returns);
+
+/* swap_and_flatten, rl_baselines/ppo2/ppo2.py:531-539: in [T,n,d] -> out [n*T,d] (env-major).  d in {1,4,12,13}. */
+int qs_swap_and_flatten(QsEnv *env, int64_t T, int64_t n, int64_t d, const float *in, float *out);
+
 /* ---- layer-1 entry points: n independent drones / controllers (n need not equal N) ----------- */
 
 /* Drone.step (dynamics/quadrotor.py:126-144): state [n,13] in/out, u_prev [n,4] in/out (Drone.u),

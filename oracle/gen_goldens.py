@@ -19,6 +19,7 @@ Fixture sets:
   g6_sim_pid        run_sim_PID.py:8-54 hover loop, 2000 steps (BASELINE config 1)
   g7_domain_rand    v0/v2 trajectories with patched mass / inertia
   g8_traj_v1        docking-v1 (construction-time chaser jitter) trajectories, three constructions
+  g10_gae           GAE(lambda) + swap_and_flatten of the in-tree PPO2 Runner (reference lines executed)
   g9_hovering       hovering-v0 trajectories (raw-state obs, own reward/done), three constructions
 """
 import importlib.util
@@ -421,7 +422,48 @@ def gen_g9(T=1200):
     save("g9_hovering", **out)
 
 
+def _ref_source_block(path, start_marker, end_marker):
+    """lines [start_marker .. end_marker] of a reference file, dedented -- executed, never stored"""
+    import textwrap
+    lines = open(os.path.join(REF, path)).read().split("\n")
+    i0 = next(i for i, l in enumerate(lines) if start_marker in l)
+    i1 = next(i for i, l in enumerate(lines) if end_marker in l and i >= i0)
+    return textwrap.dedent("\n".join(lines[i0:i1 + 1]))
+
+
+def gen_g10():
+    """GAE(lambda) + swap_and_flatten of the in-tree PPO2 Runner, rl_baselines/ppo2/ppo2.py:507-520,531-539.
+    The module itself needs TensorFlow (absent), so the generator EXECUTES those source lines of the reference
+    file as they stand, in a namespace holding the Runner's local variables."""
+    gae_src = _ref_source_block("rl_baselines/ppo2/ppo2.py", "mb_advs = np.zeros_like(mb_rewards)", "mb_returns = mb_advs + mb_values")
+    flat_src = _ref_source_block("rl_baselines/ppo2/ppo2.py", "def swap_and_flatten(arr):", "return arr.swapaxes(0, 1)")
+    ns_f = {"np": np}
+    exec(compile(flat_src, "ppo2.py:swap_and_flatten", "exec"), ns_f)
+    out = {}
+    for j, (T, N, gamma, lam, seed) in enumerate(((600, 10, 0.99, 0.95, 1), (128, 37, 0.99, 0.95, 2), (64, 130, 0.9, 1.0, 3), (5, 3, 1.0, 0.0, 4))):
+        rs = np.random.RandomState(seed)
+        mb_rewards = rs.normal(0, 1, (T, N)).astype(np.float32)
+        mb_values = rs.normal(0, 2, (T, N)).astype(np.float32)
+        mb_dones = rs.rand(T, N) < (0.03 if T > 10 else 0.3)
+        last_values = rs.normal(0, 2, N).astype(np.float32)
+        last_dones = rs.rand(N) < 0.2
+        self = types.SimpleNamespace(n_steps=T, dones=last_dones, gamma=gamma, lam=lam)
+        ns = dict(np=np, self=self, mb_rewards=mb_rewards, mb_values=mb_values, mb_dones=mb_dones, last_values=last_values)
+        exec(compile(gae_src, "ppo2.py:gae", "exec"), ns)
+        key = "c%d_" % j
+        out.update({key + "rewards": mb_rewards, key + "values": mb_values, key + "dones": mb_dones.astype(np.uint8),
+                    key + "last_values": last_values, key + "last_dones": last_dones.astype(np.uint8),
+                    key + "gamma_lam": np.array([gamma, lam]), key + "advs": ns["mb_advs"], key + "returns": ns["mb_returns"],
+                    key + "flat_returns": ns_f["swap_and_flatten"](ns["mb_returns"])})
+        if T <= 64:
+            obs = rs.normal(0, 1, (T, N, 12)).astype(np.float32)
+            out[key + "obs"] = obs
+            out[key + "flat_obs"] = ns_f["swap_and_flatten"](obs)
+        assert ns["mb_advs"].dtype == np.float32
+    save("g10_gae", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     for w in which:
         globals()["gen_" + w]()

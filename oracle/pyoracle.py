@@ -219,6 +219,16 @@ class Oracle:
         self._f("qso_ctor_init")(C.c_uint64(seed), C.c_uint64(gid), C.c_int(kind), _p(out))
         return out
 
+    def gae(self, rewards, values, dones, last_values, last_dones, gamma, lam):
+        """rl_baselines/ppo2/ppo2.py:507-520 -> (advs [T,N] f32, returns [T,N] f32)"""
+        rewards = np.ascontiguousarray(rewards, np.float32); values = np.ascontiguousarray(values, np.float32)
+        dones = np.ascontiguousarray(dones, np.uint8); T, n = rewards.shape
+        lv = np.ascontiguousarray(last_values, np.float32); ld = np.ascontiguousarray(last_dones, np.uint8)
+        advs = np.zeros((T, n), np.float32); rets = np.zeros((T, n), np.float32)
+        self._f("qso_gae")(C.c_int64(T), C.c_int64(n), _p(rewards), _p(values), _p(dones), _p(lv), _p(ld),
+                           C.c_double(gamma), C.c_double(lam), _p(advs), _p(rets))
+        return advs, rets
+
     def sim_pid(self, T, s, sdes, par=PAR_NOMINAL, dt=0.02, integ=0, u_prev=None):
         """run_sim_PID.py:43-54 loop -> (states[T,13], u[T,4], final state, final sdes)"""
         s = self._a(s, (13,)).copy(); sdes = self._a(sdes, (13,)).copy(); par = self._a(par, (4,))

@@ -830,4 +830,33 @@ void FN(qso_ctor_init)(uint64_t seed, uint64_t gid, int kind, float *init)
     }
 }
 
+/* -------------------------------------------------------------------------
+ * GAE(lambda) of the PPO2 Runner, rl_baselines/ppo2/ppo2.py:507-520.
+ * float32 rewards / values in, float32 advantages / returns out; the recurrence itself runs in
+ * double in the reference (`1.0 - bool` is float64, and the chained assignment
+ * `mb_advs[step] = last_gae_lam = ...` keeps the un-rounded value); only `self.gamma * nextvalues` is a
+ * Python float times a float32 array, i.e. a float32 product -- restated as such.
+ * dones[t] is the done flag BEFORE step t (mb_dones, :474); last_dones = self.dones after the last step.
+ * Compiled in both builds with identical float/double types (it does not depend on `real`).
+ * ---------------------------------------------------------------------- */
+void FN(qso_gae)(int64_t T, int64_t N, const float *rewards, const float *values, const uint8_t *dones,
+                 const float *last_values, const uint8_t *last_dones, double gamma, double lam,
+                 float *advs, float *returns)
+{
+    int64_t i, t;
+    for (i = 0; i < N; ++i) {
+        double last = 0.0;
+        for (t = T - 1; t >= 0; --t) {
+            double nonterm, nextv;
+            if (t == T - 1) { nonterm = 1.0 - (double)(last_dones[i] != 0); nextv = (double)last_values[i]; }   /* :512-514 */
+            else { nonterm = 1.0 - (double)(dones[(t + 1) * N + i] != 0); nextv = (double)values[(t + 1) * N + i]; } /* :516-517 */
+            double gv = (double)((float)gamma * (float)nextv);                /* float32 product */
+            double delta = (double)rewards[t * N + i] + gv * nonterm - (double)values[t * N + i];                  /* :518 */
+            last = delta + gamma * lam * nonterm * last;                                                          /* :519 */
+            advs[t * N + i] = (float)last;
+            returns[t * N + i] = advs[t * N + i] + values[t * N + i];                                              /* :520 (float32 + float32) */
+        }
+    }
+}
+
 int FN(qso_real_size)(void) { return (int)sizeof(real); }

@@ -11,9 +11,10 @@ from .envs import DockingEnv, HoveringEnv, ImitatingDockingEnv, MovingDockingEnv
 from .vec_env import C3_INIT_RANGE, VecDockingEnv, shard_range
 from . import distributed
 from .policy import MlpPolicy, rollout_with_policy
+from .rollout_buffer import compute_gae, swap_and_flatten
 
 __all__ = ["VecDockingEnv", "DockingEnv", "MovingDockingEnv", "ImitatingDockingEnv", "HoveringEnv", "Drone", "controller", "make", "register_gym_ids",
            "shard_range", "build_library", "QuadsimError", "C3_INIT_RANGE", "drone_step_batch", "ctrl_batch",
-           "rel_obs_batch", "_lib", "distributed", "MlpPolicy", "rollout_with_policy"]
+           "rel_obs_batch", "_lib", "distributed", "MlpPolicy", "rollout_with_policy", "compute_gae", "swap_and_flatten"]
 
 register_gym_ids()

@@ -20,6 +20,7 @@
 
 #include "../../include/quadsim.h"
 #include "quadsim_device.hpp"
+#include "rollout_ops.hpp"
 
 using namespace qs;
 
@@ -475,6 +476,8 @@ struct QsEnv {
     uint64_t step = 0;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float nominal_obs[12] = {0};
+    float *gae_ws = nullptr;    // workspace of the chunked GAE scan
+    size_t gae_ws_floats = 0;
     float *init = nullptr;      // stored per-env initial states (docking-v1, hovering-v0, qs_set_init_state)
     int obs_dim = 12;
     // staging for QS_IO_HOST
@@ -708,6 +711,7 @@ int qs_destroy(QsEnv *e)
     if (e->st) (void)hipFree(e->st);
     if (e->par) (void)hipFree(e->par);
     if (e->init) (void)hipFree(e->init);
+    if (e->gae_ws) (void)hipFree(e->gae_ws);
     if (e->stage) (void)hipFree(e->stage);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
@@ -1034,6 +1038,52 @@ int qs_get_init_state(QsEnv *e, float *chaser_init, float *target_init)
     CHECK_ENV(e);
     if (!e->init) return fail(QS_ERR_INVALID, "qs_get_init_state: this handle resets to the nominal / randomised state (no stored initial states)");
     return init_io(e, true, chaser_init, target_init);
+}
+
+// ---- roll-out post-processing -------------------------------------------
+int qs_gae(QsEnv *e, int64_t T, int64_t n, const float *rewards, const float *values, const uint8_t *dones,
+           const float *last_values, const uint8_t *last_dones, float gamma, float lam, float *advs, float *returns)
+{
+    CHECK_ENV(e);
+    if (T < 1 || n < 1 || !rewards || !values || !dones || !last_values || !last_dones || !advs || !returns)
+        return fail(QS_ERR_INVALID, "qs_gae: bad arguments");
+    if (e->cfg.io_space != QS_IO_DEVICE) return fail(QS_ERR_INVALID, "qs_gae: device buffers only");
+    GaeArgs G;
+    G.rewards = rewards; G.values = values; G.last_values = last_values; G.dones = dones; G.last_dones = last_dones;
+    G.advs = advs; G.returns = returns;
+    G.T = T; G.N = n; G.C = (T + kGaeChunk - 1) / kGaeChunk;
+    G.gamma = gamma; G.lam = lam;
+    const size_t need = (size_t)2 * G.C * n;
+    if (e->gae_ws_floats < need) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (e->gae_ws) HIP_TRY(hipFree(e->gae_ws));
+        e->gae_ws = nullptr; e->gae_ws_floats = 0;
+        HIP_TRY(hipMalloc((void **)&e->gae_ws, need * sizeof(float)));
+        e->gae_ws_floats = need;
+    }
+    G.ws = e->gae_ws;
+    dim3 grid((unsigned)((n + 255) / 256), (unsigned)G.C);
+    hipLaunchKernelGGL(k_gae_reduce, grid, dim3(256), 0, e->stream, G);
+    hipLaunchKernelGGL(k_gae_apply, grid, dim3(256), 0, e->stream, G);
+    HIP_TRY(hipGetLastError());
+    return QS_OK;
+}
+
+int qs_swap_and_flatten(QsEnv *e, int64_t T, int64_t n, int64_t d, const float *in, float *out)
+{
+    CHECK_ENV(e);
+    if (T < 1 || n < 1 || !in || !out) return fail(QS_ERR_INVALID, "qs_swap_and_flatten: bad arguments");
+    if (e->cfg.io_space != QS_IO_DEVICE) return fail(QS_ERR_INVALID, "qs_swap_and_flatten: device buffers only");
+    dim3 grid((unsigned)((n + 31) / 32), (unsigned)((T + 31) / 32));
+    switch (d) {
+        case 1: hipLaunchKernelGGL(k_swap_flatten<1>, grid, dim3(256), 0, e->stream, in, out, T, n); break;
+        case 4: hipLaunchKernelGGL(k_swap_flatten<4>, grid, dim3(256), 0, e->stream, in, out, T, n); break;
+        case 12: hipLaunchKernelGGL(k_swap_flatten<12>, grid, dim3(256), 0, e->stream, in, out, T, n); break;
+        case 13: hipLaunchKernelGGL(k_swap_flatten<13>, grid, dim3(256), 0, e->stream, in, out, T, n); break;
+        default: return fail(QS_ERR_INVALID, "qs_swap_and_flatten: row width %lld not supported (1, 4, 12, 13)", (long long)d);
+    }
+    HIP_TRY(hipGetLastError());
+    return QS_OK;
 }
 
 // ---- layer 1 ---------------------------------------------------------------------------------

@@ -558,3 +558,41 @@ def test_single_env_shims_v1_and_hovering(qa):
     o, r, d, info = e1.step(g8["e0_actions"][0])
     np.testing.assert_allclose(o, g8["e0_obs"][0], **OBS_TOL)
     e1.close()
+
+
+def test_g10_gae_and_swap_flatten(qa):
+    """GAE(lambda) + swap_and_flatten against the outputs of the reference's own lines (fixture g10), and at
+    roll-out size (T=600, N=65536) against the oracle on a sample of envs"""
+    import torch
+    g = load_golden("g10_gae")
+    env = qa.VecDockingEnv("docking-v0", num_envs=4)
+    for j in range(4):
+        k = "c%d_" % j
+        gamma, lam = g[k + "gamma_lam"]
+        t = lambda a: torch.as_tensor(a).cuda()            # noqa: E731
+        advs, rets = qa.compute_gae(env, t(g[k + "rewards"]), t(g[k + "values"]), t(g[k + "dones"]),
+                                    t(g[k + "last_values"]), t(g[k + "last_dones"]), gamma, lam)
+        # advantages are sums of up to T terms of O(1): absolute floor 1e-5 x their scale
+        scale = max(1.0, float(np.abs(g[k + "advs"]).max()))
+        np.testing.assert_allclose(advs.cpu().numpy(), g[k + "advs"], rtol=1e-5, atol=1e-5 * scale)
+        np.testing.assert_allclose(rets.cpu().numpy(), g[k + "returns"], rtol=1e-5, atol=1e-5 * scale)
+        flat = qa.swap_and_flatten(env, rets)
+        np.testing.assert_array_equal(flat.cpu().numpy(), rets.cpu().numpy().swapaxes(0, 1).reshape(-1))
+        if (k + "obs") in g.files:
+            fo = qa.swap_and_flatten(env, t(g[k + "obs"]))
+            np.testing.assert_array_equal(fo.cpu().numpy(), g[k + "flat_obs"])
+    # roll-out size
+    T, n = 600, 65536
+    gen = torch.Generator(device="cuda").manual_seed(0)
+    rew = torch.randn((T, n), device="cuda", generator=gen); val = 2 * torch.randn((T, n), device="cuda", generator=gen)
+    dn = (torch.rand((T, n), device="cuda", generator=gen) < 0.02)
+    lv = torch.randn(n, device="cuda", generator=gen); ld = torch.rand(n, device="cuda", generator=gen) < 0.1
+    advs, rets = qa.compute_gae(env, rew, val, dn, lv, ld, 0.99, 0.95)
+    idx = np.arange(0, n, 997)
+    a_ref, r_ref = Oracle("f64").gae(rew[:, idx].cpu().numpy(), val[:, idx].cpu().numpy(), dn[:, idx].cpu().numpy(),
+                                     lv[idx].cpu().numpy(), ld[idx].cpu().numpy(), 0.99, 0.95)
+    np.testing.assert_allclose(advs[:, idx].cpu().numpy(), a_ref, rtol=1e-5, atol=2e-4)
+    np.testing.assert_allclose(rets[:, idx].cpu().numpy(), r_ref, rtol=1e-5, atol=2e-4)
+    act = torch.randn((64, 1000, 4), device="cuda", generator=gen)
+    np.testing.assert_array_equal(qa.swap_and_flatten(env, act).cpu().numpy(), act.cpu().numpy().swapaxes(0, 1).reshape(-1, 4))
+    env.close()

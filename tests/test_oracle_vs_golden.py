@@ -231,3 +231,17 @@ def test_ctor_init_ranges(oracle64):
         h = oracle64.ctor_init(5, gid, 3)
         assert np.all(np.abs(h[0:3] - [0, 0, 5]) <= 1 + 1e-6) and abs(np.linalg.norm(h[6:10]) - 1) < 1e-6
         assert np.all(h[10:] == 0) and np.all(h[3:6] == 0)
+
+
+def test_g10_gae(oracle64):
+    """GAE(lambda) restatement vs the reference's own lines (rl_baselines/ppo2/ppo2.py:507-520)"""
+    g = load_golden("g10_gae")
+    for j in range(4):
+        k = "c%d_" % j
+        gamma, lam = g[k + "gamma_lam"]
+        advs, rets = oracle64.gae(g[k + "rewards"], g[k + "values"], g[k + "dones"], g[k + "last_values"],
+                                  g[k + "last_dones"], gamma, lam)
+        np.testing.assert_array_equal(advs, g[k + "advs"])            # same double recurrence, same float32 rounding
+        np.testing.assert_array_equal(rets, g[k + "returns"])
+        T, n = advs.shape
+        np.testing.assert_array_equal(g[k + "flat_returns"], rets.swapaxes(0, 1).reshape(T * n))
