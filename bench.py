@@ -100,7 +100,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
-    distributed = world > 1
+    distributed = world > 1 or bool(os.environ.get("QS_BENCH_FORCE_DIST"))   # the env hook rehearses the RCCL path on one GPU
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))

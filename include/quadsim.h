@@ -194,6 +194,12 @@ int qs_gae(QsEnv *env, int64_t T, int64_t n, const float *rewards, const float *
 /* swap_and_flatten, rl_baselines/ppo2/ppo2.py:531-539: in [T,n,d] -> out [n*T,d] (env-major).  d in {1,4,12,13}. */
 int qs_swap_and_flatten(QsEnv *env, int64_t T, int64_t n, int64_t d, const float *in, float *out);
 
+/* PID expert of run_expert_policy.py:49-69 / run_expert_record.py:121-136 for all N docking envs: from the handle's
+ * current chaser / target states, des_vel = kp (p_target + (-0.2,0,0) - p_chaser) + kd (-v_chaser), vel_controller on
+ * the chaser, action = (inv(rotor2control) u - action_mean) / action_std (not clipped).  state_des [N,13] in/out is
+ * the expert's persistent desired state (initialise to env.chaser_ini_state); actions [N,4] out.  Device buffers. */
+int qs_expert_action(QsEnv *env, float *state_des, float kp, float kd, float *actions);
+
 /* ---- layer-1 entry points: n independent drones / controllers (n need not equal N) ----------- */
 
 /* Drone.step (dynamics/quadrotor.py:126-144): state [n,13] in/out, u_prev [n,4] in/out (Drone.u),

@@ -19,6 +19,7 @@ Fixture sets:
   g6_sim_pid        run_sim_PID.py:8-54 hover loop, 2000 steps (BASELINE config 1)
   g7_domain_rand    v0/v2 trajectories with patched mass / inertia
   g8_traj_v1        docking-v1 (construction-time chaser jitter) trajectories, three constructions
+  g11_expert_episode PID expert (vel_controller on the chaser + inverse action map) on docking-v0
   g10_gae           GAE(lambda) + swap_and_flatten of the in-tree PPO2 Runner (reference lines executed)
   g9_hovering       hovering-v0 trajectories (raw-state obs, own reward/done), three constructions
 """
@@ -422,6 +423,37 @@ def gen_g9(T=1200):
     save("g9_hovering", **out)
 
 
+def gen_g11(total_step=900):
+    """PID expert on docking-v0: control flow transcribed from run_expert_policy.py:39-69 (the script itself needs
+    stable_baselines / a TkAgg display); every number comes from the reference's env and controller classes."""
+    env = env_v0.DockingEnv()
+    obs = env.reset()
+    control = pid.controller(env.chaser.get_arm_length(), env.chaser.get_mass())
+    state_des = env.chaser_ini_state            # aliased, as in the script (:44)
+    kp, kd = 0.35, 0
+    info_lst, O, A, U, R, D, SD, SC, ST = [], [], [], [], [], [], [], [], []
+    for t in range(total_step):
+        obss = np.array(obs).flatten()
+        state_last = info_lst[t - 1]["chaser"] if t != 0 else env.chaser_ini_state
+        des_vel = kp * (env.state_target[0:3] + np.array([-0.2, 0, 0]) - env.state_chaser[0:3]) + kd * (-env.state_chaser[3:6])
+        if t != 0:
+            state_des[3:6] = des_vel
+        SC.append(np.array(env.state_chaser)); ST.append(np.array(env.state_target))
+        action = control.vel_controller(state_des, env.state_chaser, state_last)
+        u = (np.linalg.inv(env.chaser.rotor2control) @ action - env.action_mean) / env.action_std
+        SD.append(np.array(state_des))
+        obs, reward, done, info = env.step(u)
+        O.append(obss); A.append(np.array(u)); U.append(np.array(action)); R.append(reward); D.append(done)
+        info_lst.append(info)
+        if done:
+            break
+    print("g11: steps %d, return %.4f, docked steps %d, done %s" % (len(A), float(np.sum(R)),
+          int(sum(i["flag_docking"] for i in info_lst)), D[-1]))
+    save("g11_expert_episode", obs=np.array(O), actions=np.array(A), u=np.array(U), rewards=np.array(R),
+         done=np.array(D, np.uint8), state_des_after=np.array(SD), chaser=np.array(SC), target=np.array(ST),
+         last_obs=np.array(obs), kp_kd=np.array([kp, kd]))
+
+
 def _ref_source_block(path, start_marker, end_marker):
     """lines [start_marker .. end_marker] of a reference file, dedented -- executed, never stored"""
     import textwrap
@@ -464,6 +496,6 @@ def gen_g10():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for w in which:
         globals()["gen_" + w]()

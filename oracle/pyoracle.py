@@ -229,6 +229,14 @@ class Oracle:
                            C.c_double(gamma), C.c_double(lam), _p(advs), _p(rets))
         return advs, rets
 
+    def expert_action(self, sdes, sc, st, first, kp=0.35, kd=0.0, mass=0.18):
+        """-> (action[4], u[4], mutated state_des[13])"""
+        sdes = self._a(sdes, (13,)).copy(); sc = self._a(sc, (13,)); st = self._a(st, (13,))
+        a = np.zeros(4, self.dtype); u = np.zeros(4, self.dtype)
+        self._f("qso_expert_action")(_p(sdes), _p(sc), _p(st), C.c_int(int(first)), self.creal(kp), self.creal(kd),
+                                     self.creal(mass), _p(a), _p(u))
+        return a, u, sdes
+
     def sim_pid(self, T, s, sdes, par=PAR_NOMINAL, dt=0.02, integ=0, u_prev=None):
         """run_sim_PID.py:43-54 loop -> (states[T,13], u[T,4], final state, final sdes)"""
         s = self._a(s, (13,)).copy(); sdes = self._a(sdes, (13,)).copy(); par = self._a(par, (4,))

@@ -859,4 +859,37 @@ void FN(qso_gae)(int64_t T, int64_t N, const float *rewards, const float *values
     }
 }
 
+/* -------------------------------------------------------------------------
+ * the PID expert of run_expert_policy.py:49-69 / run_expert_record.py:121-136.
+ * des_vel = kp (p_target + (-0.2,0,0) - p_chaser) + kd (-v_chaser)                      (:57)
+ * state_des[3:6] = des_vel except on the first step of an episode                       (:58-59)
+ * u = vel_controller(state_des, state_chaser, state_last)  (state_last aliases the current state: e_dv = 0)  (:60)
+ * action = (inv(rotor2control) @ u - action_mean) / action_std, NOT clipped               (:63)
+ * sdes [13] is the expert's persistent state_des (pos = the chaser's initial position; [6:12] rewritten by the
+ * controller).  `first` = first step of the episode (idx_per_epi == 0).
+ * ---------------------------------------------------------------------- */
+void FN(qso_expert_action)(real sdes[13], const real sc[13], const real st[13], int first, real kp, real kd,
+                           real mass, real action[4], real u_out[4])
+{
+    real u[4];
+    int i;
+    if (!first) {
+        sdes[3] = kp * (st[0] + (real)-0.2 - sc[0]) + kd * (-sc[3]);
+        sdes[4] = kp * (st[1] + 0 - sc[1]) + kd * (-sc[4]);
+        sdes[5] = kp * (st[2] + 0 - sc[2]) + kd * (-sc[5]);
+    }
+    FN(qso_ctrl_vel)(sdes, sc, sc, mass, u);
+    /* inverse of rotor2control (quadrotor.py:56-59) */
+    real lambda = (real)(K_KM / K_KF);
+    real f4 = u[0] / 4, a = (real)1.0 / (2 * K_L), b = (real)1.0 / (4 * lambda);
+    real f[4];
+    f[0] = f4 - a * u[2] + b * u[3];
+    f[1] = f4 + a * u[1] - b * u[3];
+    f[2] = f4 + a * u[2] + b * u[3];
+    f[3] = f4 - a * u[1] - b * u[3];
+    real mean = mass * K_G / (real)2.0;
+    for (i = 0; i < 4; ++i) action[i] = (f[i] - mean) / mean;
+    if (u_out) for (i = 0; i < 4; ++i) u_out[i] = u[i];
+}
+
 int FN(qso_real_size)(void) { return (int)sizeof(real); }

@@ -418,6 +418,47 @@ __global__ __launch_bounds__(kBlock) void k_ctrl(int64_t n, int mode, float *sta
     state_des[i * 13 + 11] = 0.0f;   // pitch_rate_des, PIDController.py:102
 }
 
+// PID expert (run_expert_policy.py:49-69, run_expert_record.py:121-136): vel_controller on the chaser towards
+// 0.2 m behind the target, inverse action map (inv(rotor2control) u - mean)/std, not clipped.  Reads the envs'
+// current chaser / target state straight from the tiles; state_des [N][13] is the expert's persistent desired
+// state (pos = chaser start, vel = des_vel, [6:12] rewritten by the controller).  First step of an episode
+// (t == 0) keeps the previous des_vel (:58-59).
+template <bool PARAMS>
+__global__ __launch_bounds__(kBlock) void k_expert_action(const float *__restrict__ st, const float *__restrict__ par, int64_t n,
+                                                          float *__restrict__ state_des, float kp, float kd, Par par_nom,
+                                                          float *__restrict__ actions)
+{
+    const int lane = threadIdx.x & (kTile - 1);
+    const int64_t tile = (int64_t)blockIdx.x * (kBlock / kTile) + (threadIdx.x >> 6);
+    const int64_t env = tile * kTile + lane;
+    if (env >= n) return;
+    const float *b = st + tile * (int64_t)(kRecWords * kTile) + lane;
+    float sc[13], tp[3], sd[13];
+    for (int i = 0; i < 13; ++i) sc[i] = b[(F_SC + i) * kTile];
+    for (int i = 0; i < 3; ++i) tp[i] = b[(F_ST + i) * kTile];
+    const float t = b[F_T * kTile];
+    for (int i = 0; i < 13; ++i) sd[i] = state_des[env * 13 + i];
+    Par P = par_nom;
+    if (PARAMS) P = load_par(par, tile, lane);
+    if (t != 0.0f) {
+        sd[3] = kp * (tp[0] - 0.2f - sc[0]) + kd * (-sc[3]);
+        sd[4] = kp * (tp[1] - sc[1]) + kd * (-sc[4]);
+        sd[5] = kp * (tp[2] - sc[2]) + kd * (-sc[5]);
+    }
+    const float dv[3] = {0.0f, 0.0f, 0.0f};        // state_last aliases the current state
+    float u[4];
+    target_control(1, sd, sd + 3, sd + 6, sd[12], sc, dv, P.m, u);
+    sd[10] = 0.0f; sd[11] = 0.0f;
+    constexpr float a = 1.0f / (2.0f * kL), bq = 1.0f / (4.0f * kLambda);
+    const float f4 = 0.25f * u[0];
+    const float f0 = f4 - a * u[2] + bq * u[3], f1 = f4 + a * u[1] - bq * u[3];
+    const float f2 = f4 + a * u[2] + bq * u[3], f3 = f4 - a * u[1] - bq * u[3];
+    const float inv_mean = q_rcp(0.5f * P.m * kG);
+    reinterpret_cast<float4 *>(actions)[env] = make_float4(f0 * inv_mean - 1.0f, f1 * inv_mean - 1.0f, f2 * inv_mean - 1.0f,
+                                                           f3 * inv_mean - 1.0f);
+    for (int i = 3; i < 12; ++i) state_des[env * 13 + i] = sd[i];
+}
+
 __global__ __launch_bounds__(kBlock) void k_rel_obs(int64_t n, const float *chaser, const float *target, float *obs)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -1082,6 +1123,21 @@ int qs_swap_and_flatten(QsEnv *e, int64_t T, int64_t n, int64_t d, const float *
         case 13: hipLaunchKernelGGL(k_swap_flatten<13>, grid, dim3(256), 0, e->stream, in, out, T, n); break;
         default: return fail(QS_ERR_INVALID, "qs_swap_and_flatten: row width %lld not supported (1, 4, 12, 13)", (long long)d);
     }
+    HIP_TRY(hipGetLastError());
+    return QS_OK;
+}
+
+int qs_expert_action(QsEnv *e, float *state_des, float kp, float kd, float *actions)
+{
+    CHECK_ENV(e);
+    if (!state_des || !actions) return fail(QS_ERR_INVALID, "qs_expert_action: null argument");
+    if (e->cfg.io_space != QS_IO_DEVICE) return fail(QS_ERR_INVALID, "qs_expert_action: device buffers only");
+    if (e->cfg.kind == QS_KIND_HOVERING_V0) return fail(QS_ERR_INVALID, "qs_expert_action: docking envs only");
+    Par pn{e->cfg.mass, e->cfg.inertia[0], e->cfg.inertia[1], e->cfg.inertia[2]};
+    if (e->per_env_params)
+        hipLaunchKernelGGL(k_expert_action<true>, dim3(grid_tiles(e->n)), dim3(kBlock), 0, e->stream, e->st, e->par, e->n, state_des, kp, kd, pn, actions);
+    else
+        hipLaunchKernelGGL(k_expert_action<false>, dim3(grid_tiles(e->n)), dim3(kBlock), 0, e->stream, e->st, e->par, e->n, state_des, kp, kd, pn, actions);
     HIP_TRY(hipGetLastError());
     return QS_OK;
 }

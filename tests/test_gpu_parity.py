@@ -596,3 +596,46 @@ def test_g10_gae_and_swap_flatten(qa):
     act = torch.randn((64, 1000, 4), device="cuda", generator=gen)
     np.testing.assert_array_equal(qa.swap_and_flatten(env, act).cpu().numpy(), act.cpu().numpy().swapaxes(0, 1).reshape(-1, 4))
     env.close()
+
+
+def test_g11_pid_expert_and_dataset(qa, tmp_path):
+    """PID expert (run_expert_policy.py:49-69) on the GPU: per-step actions from the reference's recorded states, the
+    closed-loop episode (docks, ends by time-out, return 0.8418), and the ExpertDataset writer's format."""
+    g = load_golden("g11_expert_episode")
+    T = len(g["actions"])
+    env = qa.VecDockingEnv("docking-v0", num_envs=T, auto_reset=False)
+    env.set_state(chaser=g["chaser"], target=g["target"], t=np.arange(T, dtype=np.float32))
+    ex = qa.PIDExpert(env, *g["kp_kd"])
+    import torch
+    sd_before = np.tile(np.array([8, -50, 5, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0], np.float32), (T, 1))
+    sd_before[1:] = g["state_des_after"][:-1]
+    ex.state_des.copy_(torch.as_tensor(sd_before))
+    a = ex.act().cpu().numpy()
+    # actions are (f_i - mean)/mean with f_i built from moments of O(1e-2) / (2 L): absolute floor 1e-5 x 10
+    np.testing.assert_allclose(a, g["actions"], rtol=1e-4, atol=2e-4)
+    np.testing.assert_allclose(ex.state_des.cpu().numpy(), g["state_des_after"], **STATE_TOL)
+    env.close()
+    # closed loop, 4 identical envs
+    env = qa.VecDockingEnv("docking-v0", num_envs=4, auto_reset=True)
+    ex = qa.PIDExpert(env, *g["kp_kd"])
+    obs = env.reset()
+    ret, docked = 0.0, 0
+    for t in range(T):
+        np.testing.assert_allclose(obs.cpu().numpy()[0], g["obs"][t], rtol=5e-3, atol=5e-3)
+        obs, r, d, info = env.step(ex.act())
+        ret += float(r[0]); docked += int(info.flags[0] & 1)
+        assert bool(d[0]) == bool(g["done"][t])
+    assert abs(ret - float(g["rewards"].sum())) < 2e-2 and abs(docked - 156) <= 4
+    env.close()
+    # dataset writer: SB2 ExpertDataset keys / shapes / env-major order
+    env = qa.VecDockingEnv("docking-v0", num_envs=8, auto_reset=True)
+    path = str(tmp_path / "expert.npz")
+    data = qa.record_expert_dataset(env, 700, save_path=path)
+    z = np.load(path)
+    assert sorted(z.files) == ["actions", "episode_returns", "episode_starts", "obs", "rewards"]
+    assert z["actions"].shape == (8 * 700, 4) and z["obs"].shape == (8 * 700, 12) and z["rewards"].shape == (8 * 700,)
+    assert z["episode_starts"].shape == (8 * 700,) and z["episode_starts"][0] and z["episode_starts"][700]
+    assert z["episode_starts"].sum() == 16 and len(z["episode_returns"]) == 8       # one time-out per env at t = 600
+    np.testing.assert_allclose(z["obs"][:600], g["obs"], rtol=5e-3, atol=5e-3)
+    np.testing.assert_allclose(z["episode_returns"], float(g["rewards"].sum()), atol=2e-2)
+    env.close()

@@ -245,3 +245,27 @@ def test_g10_gae(oracle64):
         np.testing.assert_array_equal(rets, g[k + "returns"])
         T, n = advs.shape
         np.testing.assert_array_equal(g[k + "flat_returns"], rets.swapaxes(0, 1).reshape(T * n))
+
+
+def test_g11_expert_episode(oracle64):
+    """PID expert (run_expert_policy.py:49-69): per-step action parity and the closed-loop episode on the oracle env"""
+    g = load_golden("g11_expert_episode")
+    kp, kd = g["kp_kd"]
+    sdes = np.array([8, -50, 5, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0], float)
+    for t in range(len(g["actions"])):
+        a, u, sdes = oracle64.expert_action(sdes, g["chaser"][t], g["target"][t], t == 0, kp, kd)
+        np.testing.assert_allclose(a, g["actions"][t], **TOL)
+        np.testing.assert_allclose(u, g["u"][t], **TOL)
+        np.testing.assert_allclose(sdes, g["state_des_after"][t], **TOL)
+    # closed loop
+    rec = oracle64.env_init(1)[0]
+    sdes = np.array([8, -50, 5, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0], float)
+    obs = oracle64.rel_obs(rec[0:13], rec[13:26])
+    ret = 0.0
+    for t in range(len(g["actions"])):
+        np.testing.assert_allclose(obs, g["obs"][t], rtol=1e-8, atol=1e-8)
+        a, u, sdes = oracle64.expert_action(sdes, rec[0:13], rec[13:26], t == 0, kp, kd)
+        rec, obs, rew, done, flags = oracle64.env_step(rec, a)
+        assert abs(rew - g["rewards"][t]) < 1e-8 and done == bool(g["done"][t])
+        ret += rew
+    assert abs(ret - 0.8418) < 1e-3 and done
