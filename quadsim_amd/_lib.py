@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("QUADSIM_HIP_LIB") or os.path.join(CSRC, "libquadsim_hip.so")  # override: A/B builds
 SOURCES = [os.path.join(CSRC, "quadsim_hip.hip")]
-HEADERS = [os.path.join(CSRC, "quadsim_device.hpp"), os.path.join(CSRC, "rollout_ops.hpp"), os.path.join(HERE, "..", "include", "quadsim.h")]
+HEADERS = [os.path.join(CSRC, "quadsim_device.hpp"), os.path.join(CSRC, "rollout_ops.hpp"), os.path.join(CSRC, "policy_rollout.hpp"), os.path.join(HERE, "..", "include", "quadsim.h")]
 
 QS_OK = 0
 KIND_V0, KIND_V2, KIND_V1, KIND_HOVER = 0, 1, 2, 3
@@ -25,7 +25,7 @@ EXPORTS = [
     "qs_config_default", "qs_version", "qs_last_error", "qs_create", "qs_destroy", "qs_reset", "qs_step",
     "qs_rollout", "qs_rollout_stepwise", "qs_fill_random_actions", "qs_get_state", "qs_set_state", "qs_set_params", "qs_get_params",
     "qs_set_init_state", "qs_get_init_state", "qs_obs_dim", "qs_get_step_counter", "qs_set_step_counter", "qs_set_stream", "qs_sync", "qs_timer_start", "qs_timer_stop",
-    "qs_drone_step", "qs_ctrl", "qs_rel_obs", "qs_gae", "qs_swap_and_flatten", "qs_expert_action",
+    "qs_drone_step", "qs_ctrl", "qs_rel_obs", "qs_gae", "qs_swap_and_flatten", "qs_expert_action", "qs_policy_rollout",
 ]
 
 
@@ -114,6 +114,7 @@ def load():
         "qs_gae": [vp, i64, i64, vp, vp, vp, vp, vp, f32, f32, vp, vp],
         "qs_swap_and_flatten": [vp, i64, i64, i64, vp, vp],
         "qs_expert_action": [vp, vp, f32, f32, vp],
+        "qs_policy_rollout": [vp, i64] + [vp] * 11,
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

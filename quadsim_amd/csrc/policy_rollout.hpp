@@ -1,0 +1,122 @@
+// policy_rollout.hpp -- policy-in-the-loop roll-out in ONE launch:
+//   for t in 0..T-1:  a_t = clip(MLP(obs_t), -1, 1);  obs_{t+1}, r_t, done_t = env.step(a_t)
+// i.e. the loop of run_trained_docking_ppo2.py:37-60 (model.predict(obs, deterministic=True); env.step(action))
+// for N envs with the actor of the shipped PPO2 model (shared_fc0 12->128, pi_fc0 128->128, pi 128->4, ReLU).
+// The MLP runs on the matrix cores with exact-f32 MFMA (v_mfma_f32_16x16x4_f32: a k-ordered fmaf chain, so the
+// network output is an ordinary float32 evaluation), the env step is the same device code as k_env.
+//
+// Orientation: every layer is computed TRANSPOSED, H^T[hidden][env] = W^T[hidden][k] . X^T[k][env], with the
+// weights as the A operand and the activations as the B operand.  An accumulator tile D (16 hidden x 16 envs) then
+// holds, in register i of lane l, hidden row 4*(l>>4)+i of env column l&15 -- exactly the (k-slot = l>>4,
+// column = l&15) placement the NEXT layer's B operand needs if its k-step "i of tile rt" is defined to sum the
+// hidden indices {16 rt + 4 g + i : g = 0..3}.  So accumulators feed the next MFMA directly: no LDS round trip, no
+// lane shuffles between layers; only the weight fetch address carries the permutation (weights sit in LDS as
+// W^T rows with a 132-float stride, one ds_read_b128 per 16 MFMAs).  Layer 3 is folded into the layer-2 loop
+// (each finished 16-row tile of H2 is immediately reduced into the 4 action rows), so H2 is never held whole.
+// Per wave and step: 96 + 1024 + 128 MFMAs = 40 k SIMD cycles -- the roll-out is bound by the f32 matrix rate.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "quadsim_device.hpp"
+
+namespace qs {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kHid = 128;      // hidden width of both layers
+constexpr int kLdW = 132;      // LDS row stride of W2^T / W3^T (floats): 132 = 128 + 4 keeps ds_read_b128 conflict-free
+constexpr int kLdW1 = 13;      // LDS row stride of W1^T (12 inputs + 1)
+
+struct MlpArgs {
+    const float *wt1;   // [128][12]  = shared_fc0 weight transposed (out, in)
+    const float *b1;    // [128]
+    const float *wt2;   // [128][128] = pi_fc0 weight transposed
+    const float *b2;    // [128]
+    const float *wt3;   // [4][128]   = pi weight transposed
+    const float *b3;    // [4]
+};
+
+constexpr size_t policy_lds_floats()
+{
+    return (size_t)kHid * kLdW + 16 * kLdW + kHid * kLdW1 + kHid + kHid + 16 + 4 * (12 * 64) + 4 * (64 * 4);
+}
+
+__device__ __forceinline__ f32x4 relu4(f32x4 v)
+{
+    return f32x4{fmaxf(v.x, 0.0f), fmaxf(v.y, 0.0f), fmaxf(v.z, 0.0f), fmaxf(v.w, 0.0f)};
+}
+
+// MLP for the 64 envs of one wave: obs (per owning lane) -> 4 actions (per owning lane), clipped to [-1,1]
+__device__ __forceinline__ void mlp_actor(const float obs[12], float act[4], const float *sW1, const float *sB1,
+                                          const float *sW2, const float *sB2, const float *sW3, const float *sB3,
+                                          float *sObs, float *sAct, int lane)
+{
+    const int c = lane & 15, g = lane >> 4;
+    // stage obs^T [12][64] so that each lane can fetch the (k, env column) element its B operand needs
+#pragma unroll
+    for (int k = 0; k < 12; ++k) sObs[k * 64 + lane] = obs[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- layer 1: H1^T [128][64] = W1^T [128][12] . obs^T [12][64]  (+ b1)
+    f32x4 h1[8][4];
+    float xb[3][4];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int et = 0; et < 4; ++et) xb[s][et] = sObs[(4 * s + g) * 64 + 16 * et + c];
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt) {
+        const f32x4 bias = *reinterpret_cast<const f32x4 *>(sB1 + 16 * rt + 4 * g);
+        float a[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) a[s] = sW1[(16 * rt + c) * kLdW1 + 4 * s + g];
+#pragma unroll
+        for (int et = 0; et < 4; ++et) {
+            f32x4 acc = bias;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], xb[s][et], acc, 0, 0, 0);
+            h1[rt][et] = relu4(acc);
+        }
+    }
+    // ---- layers 2 + 3: for each 16-row tile of H2^T: 32 k-steps over H1^T, bias, ReLU, then straight into the
+    //      action accumulators (rows 0..3 of a 16-row tile; W3^T rows 4..15 are zero)
+    f32x4 a3[4];
+    {
+        const f32x4 bias3 = *reinterpret_cast<const f32x4 *>(sB3 + 4 * g);
+#pragma unroll
+        for (int et = 0; et < 4; ++et) a3[et] = bias3;
+    }
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+        const f32x4 bias = *reinterpret_cast<const f32x4 *>(sB2 + 16 * nt + 4 * g);
+        f32x4 h2[4] = {bias, bias, bias, bias};
+#pragma unroll
+        for (int rt = 0; rt < 8; ++rt) {
+            const f32x4 w = *reinterpret_cast<const f32x4 *>(sW2 + (16 * nt + c) * kLdW + 16 * rt + 4 * g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int et = 0; et < 4; ++et)
+                    h2[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i], h1[rt][et][i], h2[et], 0, 0, 0);
+        }
+        const f32x4 w3 = *reinterpret_cast<const f32x4 *>(sW3 + c * kLdW + 16 * nt + 4 * g);
+#pragma unroll
+        for (int et = 0; et < 4; ++et) {
+            const f32x4 r = relu4(h2[et]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a3[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[i], r[i], a3[et], 0, 0, 0);
+        }
+    }
+    // rows 0..3 of the action tile live in lanes 0..15 (g == 0): hand them to the lane that owns the env
+    if (g == 0) {
+#pragma unroll
+        for (int et = 0; et < 4; ++et) *reinterpret_cast<f32x4 *>(sAct + (16 * et + c) * 4) = a3[et];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const f32x4 av = *reinterpret_cast<const f32x4 *>(sAct + lane * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) act[i] = fminf(fmaxf(av[i], -1.0f), 1.0f);
+    __builtin_amdgcn_wave_barrier();
+}
+
+}  // namespace qs

@@ -21,6 +21,7 @@
 #include "../../include/quadsim.h"
 #include "quadsim_device.hpp"
 #include "rollout_ops.hpp"
+#include "policy_rollout.hpp"
 
 using namespace qs;
 
@@ -180,6 +181,61 @@ __global__ __launch_bounds__(kBlock) void k_env(StepArgs A)
     }
     store_env(A.st, tile, lane, e);
     if (PARAMS && RMODE == 2) store_par(A.par, tile, lane, P);
+}
+
+// Policy-in-the-loop roll-out: T steps of  a = clip(MLP(obs));  obs, r, done = env.step(a)  in one launch
+// (run_trained_docking_ppo2.py:37-60 for N envs).  MLP on exact-f32 MFMA (policy_rollout.hpp), env step = the
+// device code of k_env.  obs_0 is derived from the stored state (an observation is always state2rel of the state).
+template <int INTEG, int RMODE>
+__global__ __launch_bounds__(kBlock, 1) void k_policy_rollout(StepArgs A, MlpArgs M, float *__restrict__ actions_out)
+{
+    __shared__ __attribute__((aligned(16))) float lds[policy_lds_floats()];
+    float *sW2 = lds;
+    float *sW3 = sW2 + kHid * kLdW;
+    float *sW1 = sW3 + 16 * kLdW;
+    float *sB1 = sW1 + kHid * kLdW1;
+    float *sB2 = sB1 + kHid;
+    float *sB3 = sB2 + kHid;
+    float *sObsAll = sB3 + 16;
+    float *sActAll = sObsAll + 4 * (12 * 64);
+    // weights -> LDS (W3^T rows 4..15 and b3[4..15] are zero padding of the 16-row MFMA tile)
+    for (int i = threadIdx.x; i < kHid * kHid; i += kBlock) sW2[(i >> 7) * kLdW + (i & 127)] = M.wt2[i];
+    for (int i = threadIdx.x; i < 16 * kHid; i += kBlock) sW3[(i >> 7) * kLdW + (i & 127)] = (i >> 7) < 4 ? M.wt3[i] : 0.0f;
+    for (int i = threadIdx.x; i < kHid * 12; i += kBlock) sW1[(i / 12) * kLdW1 + (i % 12)] = M.wt1[i];
+    for (int i = threadIdx.x; i < kHid; i += kBlock) { sB1[i] = M.b1[i]; sB2[i] = M.b2[i]; }
+    if (threadIdx.x < 16) sB3[threadIdx.x] = threadIdx.x < 4 ? M.b3[threadIdx.x] : 0.0f;
+    __syncthreads();
+
+    const int lane = threadIdx.x & (kTile - 1);
+    const int w = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x * (kBlock / kTile) + w;
+    const int64_t env = tile * kTile + lane;
+    const bool active = env < A.n;             // MFMA needs the whole wave: idle lanes carry a nominal env, store nothing
+    float *sObs = sObsAll + w * (12 * 64), *sAct = sActAll + w * (64 * 4);
+    Env e;
+    if (active) load_env(A.st, tile, lane, e);
+    else { nominal_init(e.sc, e.st); for (int i = 0; i < 4; ++i) { e.uc[i] = 0.0f; e.ut[i] = 0.0f; e.qd[i] = i == 0; } e.ls = 0.0f; e.t = 0.0f; }
+    Par P = A.par_nom;
+    float obs[12];
+    rel_obs(e.sc, e.st, obs);
+#pragma clang loop unroll(disable)
+    for (int64_t t = 0; t < A.T; ++t) {
+        float a[4];
+        mlp_actor(obs, a, sW1, sB1, sW2, sB2, sW3, sB3, sObs, sAct, lane);
+        float reward;
+        unsigned flags;
+        bool done;
+        step_and_maybe_reset<INTEG, false, RMODE>(e, P, a, A, active ? env : 0, A.step_idx + (uint64_t)t, obs, reward, flags, done, false);
+        if (active) {
+            const int64_t o = t * A.n + env;
+            store_obs(A.obs, o, obs);
+            A.reward[o] = reward;
+            A.done[o] = done ? 1 : 0;
+            if (A.flags) A.flags[o] = (uint8_t)flags;
+            if (actions_out) reinterpret_cast<float4 *>(actions_out)[o] = make_float4(a[0], a[1], a[2], a[3]);
+        }
+    }
+    if (active) store_env(A.st, tile, lane, e);
 }
 
 // hovering-v0 (HoveringEnv.step, hovering_env.py:47-78): T fused steps, one drone per lane.  Uses rows F_SC..
@@ -1124,6 +1180,31 @@ int qs_swap_and_flatten(QsEnv *e, int64_t T, int64_t n, int64_t d, const float *
         default: return fail(QS_ERR_INVALID, "qs_swap_and_flatten: row width %lld not supported (1, 4, 12, 13)", (long long)d);
     }
     HIP_TRY(hipGetLastError());
+    return QS_OK;
+}
+
+int qs_policy_rollout(QsEnv *e, int64_t T, const float *wt1, const float *b1, const float *wt2, const float *b2,
+                      const float *wt3, const float *b3, float *obs, float *reward, uint8_t *done, uint8_t *flags, float *actions)
+{
+    CHECK_ENV(e);
+    if (T < 1 || !wt1 || !b1 || !wt2 || !b2 || !wt3 || !b3 || !obs || !reward || !done)
+        return fail(QS_ERR_INVALID, "qs_policy_rollout: bad arguments");
+    if (e->cfg.io_space != QS_IO_DEVICE) return fail(QS_ERR_INVALID, "qs_policy_rollout: device buffers only");
+    if (!e->cfg.auto_reset) return fail(QS_ERR_INVALID, "qs_policy_rollout: requires auto_reset");
+    if (e->cfg.kind == QS_KIND_HOVERING_V0 || e->per_env_params || e->init || e->cfg.randomise > 1)
+        return fail(QS_ERR_INVALID, "qs_policy_rollout: docking-v0/v2 with nominal or rocRAND-initialised resets only");
+    StepArgs A = make_args(e);
+    A.T = T; A.obs = obs; A.reward = reward; A.done = done; A.flags = flags;
+    MlpArgs M{wt1, b1, wt2, b2, wt3, b3};
+    const unsigned grid = grid_tiles(e->n);
+    const bool fr = e->cfg.integrator == QS_INTEG_FROZEN;
+    const int rm = e->cfg.randomise;
+    if (fr && rm == 0) hipLaunchKernelGGL((k_policy_rollout<0, 0>), dim3(grid), dim3(kBlock), 0, e->stream, A, M, actions);
+    else if (fr) hipLaunchKernelGGL((k_policy_rollout<0, 1>), dim3(grid), dim3(kBlock), 0, e->stream, A, M, actions);
+    else if (rm == 0) hipLaunchKernelGGL((k_policy_rollout<1, 0>), dim3(grid), dim3(kBlock), 0, e->stream, A, M, actions);
+    else hipLaunchKernelGGL((k_policy_rollout<1, 1>), dim3(grid), dim3(kBlock), 0, e->stream, A, M, actions);
+    HIP_TRY(hipGetLastError());
+    e->step += (uint64_t)T;
     return QS_OK;
 }
 

@@ -32,6 +32,28 @@ class MlpPolicy:
         return t.clamp(t.addmm(self.b2, h, self.w2), -1.0, 1.0)
 
 
+def fused_policy_rollout(env, policy, T, want_actions=True):
+    """The same loop as rollout_with_policy in ONE kernel launch (qs_policy_rollout): MLP on the matrix cores
+    (exact-f32 MFMA) + fused env step, T steps, no host involvement.  Starts from the envs' current state.
+    Returns (obs [T,N,12], reward [T,N], done [T,N] u8, flags [T,N] u8, actions [T,N,4] or None)."""
+    import ctypes as C
+    import torch
+    from . import _lib
+    if not hasattr(policy, "_wt"):
+        policy._wt = [policy.w0.t().contiguous(), policy.b0.contiguous(), policy.w1.t().contiguous(),
+                      policy.b1.contiguous(), policy.w2.t().contiguous(), policy.b2.contiguous()]
+    n, dev = env.num_envs, env.device
+    obs = torch.empty((T, n, 12), dtype=torch.float32, device=dev)
+    rew = torch.empty((T, n), dtype=torch.float32, device=dev)
+    done = torch.empty((T, n), dtype=torch.uint8, device=dev)
+    flags = torch.empty((T, n), dtype=torch.uint8, device=dev)
+    acts = torch.empty((T, n, 4), dtype=torch.float32, device=dev) if want_actions else None
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None      # noqa: E731
+    _lib.check(env._lib.qs_policy_rollout(env._h, T, *[p(w) for w in policy._wt], p(obs), p(rew), p(done), p(flags),
+                                          p(acts)), "qs_policy_rollout")
+    return obs, rew, done, flags, acts
+
+
 def rollout_with_policy(env, policy, T, obs0=None):
     """T steps of ``a = policy(obs); obs, r, d, info = env.step(a)`` on a torch-backend VecDockingEnv.
     Returns stacked (obs [T,N,12], reward [T,N], done [T,N] bool, flags [T,N] u8, actions [T,N,4])."""

@@ -639,3 +639,37 @@ def test_g11_pid_expert_and_dataset(qa, tmp_path):
     np.testing.assert_allclose(z["obs"][:600], g["obs"], rtol=5e-3, atol=5e-3)
     np.testing.assert_allclose(z["episode_returns"], float(g["rewards"].sum()), atol=2e-2)
     env.close()
+
+
+def test_fused_policy_rollout_mfma(qa):
+    """qs_policy_rollout (MLP on exact-f32 MFMA + fused env step, one launch) against (a) the torch-GEMM loop on the
+    same envs, (b) the reference's closed-loop episode (fixture g5: docks for 183 steps, time-out, return 0.7071)"""
+    import os
+    from conftest import GOLDEN
+    g = load_golden("g5_policy_episode")
+    pol = qa.MlpPolicy.from_npz(os.path.join(GOLDEN, "policy_best_model_v0.npz"))
+    # (a) 1000 envs with rocRAND-jittered starts, 48 steps: same actions / observations as the per-step loop
+    kw = dict(num_envs=1000, randomise=1, seed=5, init_range=qa.C3_INIT_RANGE)
+    e1 = qa.VecDockingEnv("docking-v0", **kw); e2 = qa.VecDockingEnv("docking-v0", **kw)
+    o1 = e1.reset(); e2.reset()
+    O2, R2, D2, F2, A2 = qa.fused_policy_rollout(e2, pol, 48)
+    O1, R1, D1, F1, A1 = qa.rollout_with_policy(e1, pol, 48, obs0=o1)
+    np.testing.assert_allclose(A2[0].cpu().numpy(), A1[0].cpu().numpy(), atol=2e-6)       # same obs -> same MLP output
+    same = (D1.cpu().numpy() == D2.cpu().numpy().astype(bool)).all(axis=0)
+    assert same.mean() > 0.99
+    np.testing.assert_allclose(A2.cpu().numpy()[:, same], A1.cpu().numpy()[:, same], atol=2e-3)
+    np.testing.assert_allclose(O2.cpu().numpy()[:, same], O1.cpu().numpy()[:, same], rtol=2e-3, atol=2e-3)
+    s1, s2 = e1.get_state(), e2.get_state()
+    np.testing.assert_allclose(s2["chaser"][same], s1["chaser"][same], rtol=2e-3, atol=2e-3)
+    assert e1.step_counter == e2.step_counter == 48
+    e1.close(); e2.close()
+    # (b) the reference episode, ragged N (tail lanes idle inside the MFMA wave)
+    env = qa.VecDockingEnv("docking-v0", num_envs=70, auto_reset=True)
+    env.reset()
+    O, R, D, F, A = (x.cpu().numpy() for x in qa.fused_policy_rollout(env, pol, 600))
+    env.close()
+    assert np.all(O[:, 0] == O[:, 69])
+    np.testing.assert_allclose(A[:, 0], g["actions"], atol=5e-3)
+    np.testing.assert_allclose(O[:599, 0], g["obs"][:599], atol=2e-3)
+    assert abs(float(R[:, 0].sum()) - float(g["reward"].sum())) < 5e-3
+    assert abs(int((F[:, 0] & 1).sum()) - 183) <= 3 and D[599, 0] and not D[:599, 0].any()

@@ -67,4 +67,14 @@ us = timed(loop, 300, 20)
 out["policy_in_the_loop_torch_gemm"] = {"us_per_step": us, "env_steps_per_s": N / us * 1e6,
                                         "mlp_flop_per_env_step": 2 * (12 * 128 + 128 * 128 + 128 * 4)}
 env.close()
+for n in (65536, 262144):
+    env = qa.VecDockingEnv("docking-v0", num_envs=n, randomise=1, seed=1, init_range=qa.C3_INIT_RANGE)
+    env.reset()
+    T = 32
+    us = timed(lambda: qa.fused_policy_rollout(env, pol, T, want_actions=False), 5, 2) / T
+    flop = 2 * (12 * 128 + 128 * 128 + 128 * 4)
+    out["policy_in_the_loop_fused_mfma_N%d" % n] = {"us_per_step": us, "env_steps_per_s": n / us * 1e6,
+        "mlp_tflops": n * flop / (us * 1e-6) / 1e12, "mfma_f32_peak_tflops": 157.3,
+        "mfma_frac": n * flop / (us * 1e-6) / 1e12 / 157.3}
+    env.close()
 print(json.dumps(out, indent=1))
