@@ -1150,6 +1150,13 @@ int qs_gae(QsEnv *e, int64_t T, int64_t n, const float *rewards, const float *va
     G.advs = advs; G.returns = returns;
     G.T = T; G.N = n; G.C = (T + kGaeChunk - 1) / kGaeChunk;
     G.gamma = gamma; G.lam = lam;
+    if (n >= 16384) {
+        // wide batch: enough lanes to cover the latency of a T-long serial walk; read everything once
+        G.ws = nullptr;
+        hipLaunchKernelGGL(k_gae_serial, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, G);
+        HIP_TRY(hipGetLastError());
+        return QS_OK;
+    }
     const size_t need = (size_t)2 * G.C * n;
     if (e->gae_ws_floats < need) {
         HIP_TRY(hipStreamSynchronize(e->stream));
@@ -1174,8 +1181,8 @@ int qs_swap_and_flatten(QsEnv *e, int64_t T, int64_t n, int64_t d, const float *
     dim3 grid((unsigned)((n + 31) / 32), (unsigned)((T + 31) / 32));
     switch (d) {
         case 1: hipLaunchKernelGGL(k_swap_flatten<1>, grid, dim3(256), 0, e->stream, in, out, T, n); break;
-        case 4: hipLaunchKernelGGL(k_swap_flatten<4>, grid, dim3(256), 0, e->stream, in, out, T, n); break;
-        case 12: hipLaunchKernelGGL(k_swap_flatten<12>, grid, dim3(256), 0, e->stream, in, out, T, n); break;
+        case 4: hipLaunchKernelGGL(k_swap_flatten_v4<1>, grid, dim3(256), 0, e->stream, (const float4 *)in, (float4 *)out, T, n); break;
+        case 12: hipLaunchKernelGGL(k_swap_flatten_v4<3>, grid, dim3(256), 0, e->stream, (const float4 *)in, (float4 *)out, T, n); break;
         case 13: hipLaunchKernelGGL(k_swap_flatten<13>, grid, dim3(256), 0, e->stream, in, out, T, n); break;
         default: return fail(QS_ERR_INVALID, "qs_swap_and_flatten: row width %lld not supported (1, 4, 12, 13)", (long long)d);
     }

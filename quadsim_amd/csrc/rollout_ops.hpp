@@ -70,6 +70,50 @@ __global__ __launch_bounds__(256) void k_gae_apply(GaeArgs G)
     }
 }
 
+// Single-pass variant for wide batches: one lane walks one env's whole T-step chain, 16 steps at a time: the 48
+// loads of a group are issued before its 16 dependent fmas, so every wave keeps ~9 KiB in flight and the data
+// is read exactly once (17 B per (t, env) instead of 26 B for the two-pass scan).
+constexpr int kGaeGroup = 16;
+__global__ __launch_bounds__(256) void k_gae_serial(GaeArgs G)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= G.N) return;
+    float A = 0.0f;
+    float nextv = G.last_values[i];
+    float nonterm = G.last_dones[i] ? 0.0f : 1.0f;
+    int64_t t = G.T - 1;
+    const float gl = G.gamma * G.lam;
+    for (; t >= kGaeGroup - 1; t -= kGaeGroup) {
+        float r[kGaeGroup], v[kGaeGroup];
+        uint8_t d[kGaeGroup];
+#pragma unroll
+        for (int j = 0; j < kGaeGroup; ++j) {
+            const int64_t o = (t - j) * G.N + i;
+            r[j] = G.rewards[o]; v[j] = G.values[o]; d[j] = G.dones[o];
+        }
+#pragma unroll
+        for (int j = 0; j < kGaeGroup; ++j) {
+            const float delta = r[j] + (G.gamma * nextv) * nonterm - v[j];
+            A = fmaf(gl * nonterm, A, delta);
+            const int64_t o = (t - j) * G.N + i;
+            G.advs[o] = A;
+            G.returns[o] = A + v[j];
+            nextv = v[j];
+            nonterm = d[j] ? 0.0f : 1.0f;          // dones[t] gates the step before it (:516)
+        }
+    }
+    for (; t >= 0; --t) {
+        const int64_t o = t * G.N + i;
+        const float r = G.rewards[o], v = G.values[o];
+        const float delta = r + (G.gamma * nextv) * nonterm - v;
+        A = fmaf(gl * nonterm, A, delta);
+        G.advs[o] = A;
+        G.returns[o] = A + v;
+        nextv = v;
+        nonterm = G.dones[o] ? 0.0f : 1.0f;
+    }
+}
+
 // swap_and_flatten (ppo2.py:531-539): in [T][N][D] -> out [N][T][D].  32 x 32 tile of D-float rows staged in
 // LDS so that both the global reads (rows of consecutive envs) and writes (rows of consecutive steps) are
 // contiguous runs of 32*D floats.
@@ -89,6 +133,26 @@ __global__ __launch_bounds__(256) void k_swap_flatten(const float *__restrict__ 
         const int tt = r / D, d = r - tt * D;
         const int64_t i = i0 + ii, t = t0 + tt;
         if (t < T && i < N) out[(i * T + t0) * D + r] = tile[tt][ii * D + d];
+    }
+}
+
+// float4 flavour for row widths that are multiples of 4 floats (actions D=4, observations D=12): the same
+// 32 x 32 tile, moved 16 B per lane
+template <int D4>
+__global__ __launch_bounds__(256) void k_swap_flatten_v4(const float4 *__restrict__ in, float4 *__restrict__ out, int64_t T, int64_t N)
+{
+    __shared__ float4 tile[32][32 * D4 + 1];
+    const int64_t i0 = (int64_t)blockIdx.x * 32, t0 = (int64_t)blockIdx.y * 32;
+    const int ni = (int)min((int64_t)32, N - i0), nt = (int)min((int64_t)32, T - t0);
+    for (int idx = threadIdx.x; idx < 32 * 32 * D4; idx += 256) {
+        const int tt = idx / (32 * D4), r = idx - tt * (32 * D4);      // r = ii*D4 + q
+        if (tt < nt && r < ni * D4) tile[tt][r] = in[((t0 + tt) * N + i0) * D4 + r];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 32 * 32 * D4; idx += 256) {
+        const int ii = idx / (32 * D4), r = idx - ii * (32 * D4);      // r = tt*D4 + q
+        const int tt = r / D4, q = r - tt * D4;
+        if (ii < ni && tt < nt) out[((i0 + ii) * T + t0) * D4 + r] = tile[tt][ii * D4 + q];
     }
 }
 

@@ -49,7 +49,7 @@ dn = torch.rand((T, N), device="cuda", generator=g) < 0.02
 lv = torch.randn(N, device="cuda", generator=g); ld = torch.rand(N, device="cuda", generator=g) < 0.1
 dn8, ld8 = dn.to(torch.uint8), ld.to(torch.uint8)
 us = timed(lambda: qa.compute_gae(env, rew, val, dn8, lv, ld8, 0.99, 0.95), 20, 3)
-gae_bytes = T * N * (2 * (4 + 4 + 1) + 8)        # two passes over rewards/values/dones + advs/returns written once
+gae_bytes = T * N * ((4 + 4 + 1) + 8)            # single-pass kernel (N >= 16384): rewards/values/dones read once, advs/returns written
 out["gae_T600"] = {"us": us, "elements_per_s": T * N / us * 1e6, "bytes": gae_bytes, "hbm_frac": gae_bytes / (us * 1e-6) / 1e9 / PEAK}
 obs = torch.randn((T, N, 12), device="cuda", generator=g)
 us = timed(lambda: qa.swap_and_flatten(env, obs), 10, 2)
