@@ -44,6 +44,9 @@ def parse():
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--no-extras", action="store_true", help="skip the rollout_fused / rk4 / allgather legs")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
+    p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                   help="nccl (= RCCL over xGMI, the real thing) or gloo (rehearsal of the multi-rank control flow, "
+                        "e.g. several ranks sharing one GPU; skips the all-gather leg)")
     return p.parse_args()
 
 
@@ -99,11 +102,16 @@ def main():
         raise SystemExit("WORLD_SIZE=%d but --gpus=%d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    if args.backend == "gloo":
+        local_rank = local_rank % torch.cuda.device_count()          # rehearsal: ranks may share a GPU
     torch.cuda.set_device(local_rank)
     distributed = world > 1 or bool(os.environ.get("QS_BENCH_FORCE_DIST"))   # the env hook rehearses the RCCL path on one GPU
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import ctypes as C
     from quadsim_amd import C3_INIT_RANGE, VecDockingEnv, _lib, shard_range
@@ -128,7 +136,7 @@ def main():
     def max_over_ranks(x):
         if not distributed:
             return x
-        t = torch.tensor([x], dtype=torch.float64, device="cuda")
+        t = torch.tensor([x], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
@@ -224,7 +232,7 @@ def main():
         out["other_integrator"] = {"integrator": other, "value": total_envs * Ko / w3, "unit": "env-steps/s",
                                    "launch_period_us": ms3 * 1e3 / Ko}
         env_o.close()
-        if distributed:
+        if distributed and args.backend == "nccl":
             # BASELINE configs 4/5: RCCL all-gather of the roll-out slabs (obs, reward, done) once per T-step roll-out
             from quadsim_amd.distributed import gather_rollout
             o_, r_, d_, _f = env.rollout(acts, want_flags=False)

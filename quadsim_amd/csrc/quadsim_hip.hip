@@ -27,7 +27,10 @@ using namespace qs;
 
 namespace {
 
-constexpr int kBlock = 256;  // 4 wavefronts = 4 tiles per workgroup
+#ifndef QS_BLOCK
+#define QS_BLOCK 256
+#endif
+constexpr int kBlock = QS_BLOCK;  // 4 wavefronts = 4 tiles per workgroup
 
 struct StepArgs {
     float *st;             // [tiles][40][64]
