@@ -227,6 +227,11 @@ int qs_ctrl(QsEnv *env, int64_t n, int32_t mode, float *state_des, const float *
  * chaser [n,13], target [n,13] -> obs [n,12] */
 int qs_rel_obs(QsEnv *env, int64_t n, const float *chaser, const float *target, float *obs);
 
+/* ---- layer 0: utils/transform.py for n inputs -------------------------------------------------
+ * op 0 quat2euler [n,4] -> [n,3] (transform.py:94-120); 1 euler2quat [n,3] -> [n,4] (:123-136);
+ * 2 quat2rot [n,4] -> [n,9] row-major (:4-20; the reference's element-wise form); 3 rot2euler [n,9] -> [n,3] (:23-46) */
+int qs_transform(QsEnv *env, int32_t op, int64_t n, const float *in, float *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,7 +6,7 @@ library and a GPU.
 """
 from . import _lib
 from ._lib import QuadsimError, build_library
-from .drone import Drone, controller, ctrl_batch, drone_step_batch, rel_obs_batch
+from .drone import Drone, controller, ctrl_batch, drone_step_batch, rel_obs_batch, transform_batch
 from .envs import DockingEnv, HoveringEnv, ImitatingDockingEnv, MovingDockingEnv, make, register_gym_ids
 from .vec_env import C3_INIT_RANGE, VecDockingEnv, shard_range
 from . import distributed
@@ -16,6 +16,6 @@ from .expert import PIDExpert, record_expert_dataset
 
 __all__ = ["VecDockingEnv", "DockingEnv", "MovingDockingEnv", "ImitatingDockingEnv", "HoveringEnv", "Drone", "controller", "make", "register_gym_ids",
            "shard_range", "build_library", "QuadsimError", "C3_INIT_RANGE", "drone_step_batch", "ctrl_batch",
-           "rel_obs_batch", "_lib", "distributed", "MlpPolicy", "rollout_with_policy", "fused_policy_rollout", "compute_gae", "swap_and_flatten", "PIDExpert", "record_expert_dataset"]
+           "rel_obs_batch", "transform_batch", "_lib", "distributed", "MlpPolicy", "rollout_with_policy", "fused_policy_rollout", "compute_gae", "swap_and_flatten", "PIDExpert", "record_expert_dataset"]
 
 register_gym_ids()

@@ -518,6 +518,34 @@ __global__ __launch_bounds__(kBlock) void k_expert_action(const float *__restric
     for (int i = 3; i < 12; ++i) state_des[env * 13 + i] = sd[i];
 }
 
+// layer 0: utils/transform.py as batch functions.  op 0 quat2euler [n,4]->[n,3] (:94-120), 1 euler2quat [n,3]->[n,4]
+// (:123-136), 2 quat2rot [n,4]->[n,9] (:4-20), 3 rot2euler [n,9]->[n,3] (:23-46)
+__global__ __launch_bounds__(kBlock) void k_transform(int op, int64_t n, const float *in, float *out)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    if (op == 0) {
+        float q[4] = {in[i * 4], in[i * 4 + 1], in[i * 4 + 2], in[i * 4 + 3]};
+        quat2euler(q, out[i * 3], out[i * 3 + 1], out[i * 3 + 2]);
+    } else if (op == 1) {
+        float q[4];
+        euler2quat(in[i * 3], in[i * 3 + 1], in[i * 3 + 2], q);
+        for (int j = 0; j < 4; ++j) out[i * 4 + j] = q[j];
+    } else if (op == 2) {
+        float q[4] = {in[i * 4], in[i * 4 + 1], in[i * 4 + 2], in[i * 4 + 3]};
+        Rot R = quat2rot(q);
+        const float r[9] = {1.0f, R.r01, R.r02, R.r10, 1.0f, R.r12, R.r20, R.r21, 1.0f};
+        for (int j = 0; j < 9; ++j) out[i * 9 + j] = r[j];
+    } else {
+        const float *R = in + i * 9;
+        const float r12 = R[5];
+        const bool sat = (r12 >= 1.0f) || (r12 < -1.0f);
+        out[i * 3] = q_asin(fminf(fmaxf(r12, -1.0f), 1.0f));
+        out[i * 3 + 1] = sat ? 0.0f : q_atan2(-R[2], R[8]);
+        out[i * 3 + 2] = q_atan2(-R[3], R[4]);
+    }
+}
+
 __global__ __launch_bounds__(kBlock) void k_rel_obs(int64_t n, const float *chaser, const float *target, float *obs)
 {
     const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -1289,6 +1317,30 @@ int qs_ctrl(QsEnv *e, int64_t n, int32_t mode, float *state_des, const float *st
     if (e->cfg.io_space == QS_IO_HOST) {
         HIP_TRY(hipMemcpyAsync(state_des, dsd, n * 52, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipMemcpyAsync(u_out, duo, n * 16, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+    }
+    return QS_OK;
+}
+
+int qs_transform(QsEnv *e, int32_t op, int64_t n, const float *in, float *out)
+{
+    CHECK_ENV(e);
+    if (n < 1 || !in || !out || op < 0 || op > 3) return fail(QS_ERR_INVALID, "qs_transform: bad arguments");
+    const int wi[4] = {4, 3, 4, 9}, wo[4] = {3, 4, 9, 3};
+    const float *di = in;
+    float *dout = out;
+    if (e->cfg.io_space == QS_IO_HOST) {
+        int r = ensure_stage(e, (size_t)n * (wi[op] + wo[op]) * 4 + 1024);
+        if (r) return r;
+        Stage S{(char *)e->stage};
+        float *a = S.take<float>(n * wi[op]), *b = S.take<float>(n * wo[op]);
+        HIP_TRY(hipMemcpyAsync(a, in, n * wi[op] * 4, hipMemcpyHostToDevice, e->stream));
+        di = a; dout = b;
+    }
+    hipLaunchKernelGGL(k_transform, dim3(grid_flat(n)), dim3(kBlock), 0, e->stream, (int)op, n, di, dout);
+    HIP_TRY(hipGetLastError());
+    if (e->cfg.io_space == QS_IO_HOST) {
+        HIP_TRY(hipMemcpyAsync(out, dout, n * wo[op] * 4, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
     }
     return QS_OK;

@@ -78,6 +78,19 @@ def rel_obs_batch(chaser, target, device=0):
     return obs
 
 
+_TRANSFORM = {"quat2euler": (0, 4, 3), "euler2quat": (1, 3, 4), "quat2rot": (2, 4, 9), "rot2euler": (3, 9, 3)}
+
+
+def transform_batch(name, x, device=0):
+    """utils/transform.py on the GPU for n inputs: 'quat2euler' [n,4]->[n,3], 'euler2quat' [n,3]->[n,4],
+    'quat2rot' [n,4]->[n,3,3], 'rot2euler' [n,3,3]->[n,3]"""
+    op, wi, wo = _TRANSFORM[name]
+    x = _f32(x, (-1, wi))
+    out = np.zeros((x.shape[0], wo), np.float32)
+    _lib.check(_lib.load().qs_transform(_context(device), op, x.shape[0], _p(x), _p(out)), "qs_transform")
+    return out.reshape(-1, 3, 3) if name == "quat2rot" else out
+
+
 class Drone:
     """dynamics/quadrotor.py:5-63 attribute surface + reset/step on the GPU."""
 

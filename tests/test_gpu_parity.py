@@ -673,3 +673,40 @@ def test_fused_policy_rollout_mfma(qa):
     np.testing.assert_allclose(O[:599, 0], g["obs"][:599], atol=2e-3)
     assert abs(float(R[:, 0].sum()) - float(g["reward"].sum())) < 5e-3
     assert abs(int((F[:, 0] & 1).sum()) - 183) <= 3 and D[599, 0] and not D[:599, 0].any()
+
+
+def test_g2_transforms_golden_and_math_accuracy(qa):
+    """utils/transform.py on the GPU against the reference's own outputs (fixture g2, incl. the saturation
+    branches), plus the accuracy of the bounded-range asin / atan2 / sincos over their whole argument range"""
+    g = load_golden("g2_transforms")
+    q = g["quat"]
+    e = qa.transform_batch("quat2euler", q)
+    r12 = 2 * (q[:, 0] * q[:, 1] + q[:, 2] * q[:, 3])
+    knife = np.abs(np.abs(r12) - 1.0) < 1e-5             # branch point of the saturation test
+    # asin is ill-conditioned at +-1 (d asin = dx / sqrt(1 - x^2)): allow the fp32 input rounding to act
+    tol = 2e-6 + 3e-7 / np.sqrt(np.maximum(1 - np.minimum(r12 ** 2, 1), 1e-7))
+    assert np.all(np.abs(e[~knife, 0] - g["quat2euler"][~knife, 0]) <= tol[~knife])
+    np.testing.assert_allclose(e[~knife, 1:], g["quat2euler"][~knife, 1:], rtol=0, atol=4e-6)
+    np.testing.assert_allclose(qa.transform_batch("euler2quat", g["euler"]), g["euler2quat"], rtol=0, atol=5e-7)
+    np.testing.assert_allclose(qa.transform_batch("quat2rot", q), g["quat2rot"], rtol=2e-6, atol=2e-6)
+    R = g["rot"]
+    knife = np.abs(np.abs(R[:, 1, 2]) - 1.0) < 1e-5
+    er = qa.transform_batch("rot2euler", R)
+    tolr = 2e-6 + 3e-7 / np.sqrt(np.maximum(1 - np.minimum(R[:, 1, 2] ** 2, 1), 1e-7))
+    assert np.all(np.abs(er[~knife, 0] - g["rot2euler"][~knife, 0]) <= tolr[~knife])
+    np.testing.assert_allclose(er[~knife, 1:], g["rot2euler"][~knife, 1:], rtol=0, atol=4e-6)
+    assert (np.abs(R[:, 1, 2]) >= 1).sum() > 50
+    # math accuracy: euler2quat exposes sincos(x/2); quat2euler of (cos a/2, sin a/2, 0, 0) exposes asin/atan2
+    x = np.linspace(-12.0, 12.0, 200001).astype(np.float32).astype(np.float64)     # references on the f32-rounded inputs
+    eq = qa.transform_batch("euler2quat", np.stack([x, 0 * x, 0 * x], 1))
+    assert np.abs(eq[:, 0] - np.cos(x / 2)).max() < 1.5e-7 and np.abs(eq[:, 1] - np.sin(x / 2)).max() < 1.5e-7
+    a = np.linspace(-np.pi, np.pi, 200001)
+    yaw = qa.transform_batch("quat2euler", np.stack([np.cos(a / 2), 0 * a, 0 * a, np.sin(a / 2)], 1))[:, 2]
+    # the reference's convention: psi = atan2(-r10, r11) = atan2(2wz, w^2 - z^2) = a
+    assert np.abs(np.angle(np.exp(1j * (yaw - a)))).max() < 6e-7
+    s = np.linspace(-1, 1, 200001)
+    # quat (w,x,0,0) with 2wx = s, w^2 - x^2 anything: phi = asin(s)
+    w = np.sqrt((1 + np.sqrt(1 - s ** 2)) / 2); xx = s / (2 * w)
+    phi = qa.transform_batch("quat2euler", np.stack([w, xx, 0 * s, 0 * s], 1))[:, 0]
+    inner = np.abs(s) < 0.999
+    assert np.abs(phi[inner] - np.arcsin(s[inner])).max() < 3e-6
