@@ -232,6 +232,21 @@ def main():
         out["other_integrator"] = {"integrator": other, "value": total_envs * Ko / w3, "unit": "env-steps/s",
                                    "launch_period_us": ms3 * 1e3 / Ko}
         env_o.close()
+        # the same step kernel where it is not latency-bound: 1 048 576 envs per GPU (168 MB of state, 16 waves per
+        # SIMD): shows the kernel's bandwidth ceiling beside the 65 536-env headline
+        if n < (1 << 20):
+            nb = 1 << 20
+            env_b = VecDockingEnv(args.env, num_envs=nb, device=local_rank, integrator=args.integrator,
+                                  randomise=args.randomise, seed=1234, env_id_offset=rank * nb, init_range=C3_INIT_RANGE,
+                                  mass_scale=(0.8, 1.2), inertia_scale=(0.8, 1.2))
+            env_b.reset()
+            pool_b = env_b.random_actions(8, step0=0)
+            wb, msb = time_steps(env_b, 200, 20, pool_b)
+            out["step_api_1M_envs"] = {"envs_per_gpu": nb, "value": nb * world * 200 / wb, "unit": "env-steps/s",
+                                       "launch_period_us": msb * 1e3 / 200,
+                                       "hbm_frac": bpe * nb / (msb * 1e-3 / 200) / 1e9 / HBM_PEAK_GBS}
+            env_b.close()
+            del pool_b
         if distributed and args.backend == "nccl":
             # BASELINE configs 4/5: RCCL all-gather of the roll-out slabs (obs, reward, done) once per T-step roll-out
             from quadsim_amd.distributed import gather_rollout
