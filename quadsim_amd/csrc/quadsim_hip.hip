@@ -43,7 +43,8 @@ struct StepArgs {
     float *term_obs;       // nullable, [N,12] (T == 1 only)
     int64_t n;
     int64_t T;             // rollout length (1 for step)
-    uint64_t step_idx;     // global step counter of the first step
+    uint64_t step_idx;     // explicit step index (k_fill_actions); the env kernels read the device counter below
+    unsigned long long *ctr;   // device: global step counter k, one copy per tile [tiles]
     uint64_t gid0;         // global id of env 0
     EnvConst C;
     RandCfg rc;
@@ -111,6 +112,16 @@ __device__ __forceinline__ void store_obs(float *__restrict__ obs, int64_t env, 
 }
 
 // one env.step for the lane's env + VecEnv auto-reset; shared by step and rollout kernels
+// The global step counter k lives in device memory so that a captured launch (hipGraph / torch.cuda.graphs) advances
+// it on every replay.  It is kept PER TILE (one 64-bit word per wavefront's tile; all tiles hold the same value):
+// a wave reads its own word at the start and writes k + T back at the end, so no workgroup ever waits for or
+// races with another one.  (A single shared word updated through a per-workgroup ticket cost 2 us per launch.)
+__device__ __forceinline__ uint64_t step_counter_begin(const StepArgs &A, int64_t tile) { return A.ctr[tile]; }
+__device__ __forceinline__ void step_counter_end(const StepArgs &A, int64_t tile, int lane, uint64_t k)
+{
+    if (lane == 0) A.ctr[tile] = k + (uint64_t)A.T;
+}
+
 // RMODE (compile time) = the handle's `randomise`: 0 nominal reset, 1 rocRAND init state, 2 + params.
 template <int INTEG, bool PARAMS, int RMODE>
 __device__ __forceinline__ void step_and_maybe_reset(Env &e, Par &P, const float a[4], const StepArgs &A, int64_t env,
@@ -158,13 +169,14 @@ __global__ __launch_bounds__(kBlock) void k_env(StepArgs A)
     const int64_t tile = (int64_t)blockIdx.x * (kBlock / kTile) + (threadIdx.x >> 6);
     const int64_t env = tile * kTile + lane;
     if (env >= A.n) return;
+    const uint64_t k0 = step_counter_begin(A, tile);
     Env e;
     load_env(A.st, tile, lane, e);
     Par P = A.par_nom;
     if (PARAMS) P = load_par(A.par, tile, lane);
 #pragma clang loop unroll(disable)
     for (int64_t t = 0; t < A.T; ++t) {
-        const uint64_t k = A.step_idx + (uint64_t)t;
+        const uint64_t k = k0 + (uint64_t)t;
         const int64_t o = t * A.n + env;
         float a[4];
         if (A.actions) {
@@ -184,6 +196,7 @@ __global__ __launch_bounds__(kBlock) void k_env(StepArgs A)
     }
     store_env(A.st, tile, lane, e);
     if (PARAMS && RMODE == 2) store_par(A.par, tile, lane, P);
+    step_counter_end(A, tile, lane, k0);
 }
 
 // Policy-in-the-loop roll-out: T steps of  a = clip(MLP(obs));  obs, r, done = env.step(a)  in one launch
@@ -219,6 +232,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_policy_rollout(StepArgs A, MlpArg
     if (active) load_env(A.st, tile, lane, e);
     else { nominal_init(e.sc, e.st); for (int i = 0; i < 4; ++i) { e.uc[i] = 0.0f; e.ut[i] = 0.0f; e.qd[i] = i == 0; } e.ls = 0.0f; e.t = 0.0f; }
     Par P = A.par_nom;
+    const uint64_t k0 = active ? step_counter_begin(A, tile) : 0;
     float obs[12];
     rel_obs(e.sc, e.st, obs);
 #pragma clang loop unroll(disable)
@@ -228,7 +242,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_policy_rollout(StepArgs A, MlpArg
         float reward;
         unsigned flags;
         bool done;
-        step_and_maybe_reset<INTEG, false, RMODE>(e, P, a, A, active ? env : 0, A.step_idx + (uint64_t)t, obs, reward, flags, done, false);
+        step_and_maybe_reset<INTEG, false, RMODE>(e, P, a, A, active ? env : 0, k0 + (uint64_t)t, obs, reward, flags, done, false);
         if (active) {
             const int64_t o = t * A.n + env;
             store_obs(A.obs, o, obs);
@@ -238,7 +252,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_policy_rollout(StepArgs A, MlpArg
             if (actions_out) reinterpret_cast<float4 *>(actions_out)[o] = make_float4(a[0], a[1], a[2], a[3]);
         }
     }
-    if (active) store_env(A.st, tile, lane, e);
+    if (active) { store_env(A.st, tile, lane, e); step_counter_end(A, tile, lane, k0); }
 }
 
 // hovering-v0 (HoveringEnv.step, hovering_env.py:47-78): T fused steps, one drone per lane.  Uses rows F_SC..
@@ -251,6 +265,7 @@ __global__ __launch_bounds__(kBlock) void k_hover(StepArgs A)
     const int64_t tile = (int64_t)blockIdx.x * (kBlock / kTile) + (threadIdx.x >> 6);
     const int64_t env = tile * kTile + lane;
     if (env >= A.n) return;
+    const uint64_t k0 = step_counter_begin(A, tile);
     float *b = A.st + tile * (int64_t)(kRecWords * kTile) + lane;
     float s[13], up[4];
 #pragma unroll
@@ -267,7 +282,7 @@ __global__ __launch_bounds__(kBlock) void k_hover(StepArgs A)
             const float4 av = reinterpret_cast<const float4 *>(A.actions)[o];
             a[0] = av.x; a[1] = av.y; a[2] = av.z; a[3] = av.w;
         } else {
-            random_action(A.rc.seed, A.gid0 + (uint64_t)env, A.step_idx + (uint64_t)t, a);
+            random_action(A.rc.seed, A.gid0 + (uint64_t)env, k0 + (uint64_t)t, a);
 #pragma unroll
             for (int i = 0; i < 4; ++i) a[i] = 0.5f * a[i] + 0.5f;    // hovering actions live in [0,1]
         }
@@ -293,6 +308,7 @@ __global__ __launch_bounds__(kBlock) void k_hover(StepArgs A)
     for (int i = 0; i < 13; ++i) b[(F_SC + i) * kTile] = s[i];
 #pragma unroll
     for (int i = 0; i < 4; ++i) b[(F_UC + i) * kTile] = up[i];
+    step_counter_end(A, tile, lane, k0);
 }
 
 // construction-time jitter of docking-v1 (imitating_docking_env.py:34: chaser pos += U(-0.3,0.3)^3) and
@@ -351,7 +367,7 @@ __global__ __launch_bounds__(kBlock) void k_reset(StepArgs A, const uint8_t *__r
         for (int i = 0; i < 13; ++i) { ic[i] = src[i]; it[i] = src[13 + i]; }
     } else if (A.randomise) {
         Par Pn;
-        random_init<true>(A.rc, STREAM_RESET, A.gid0 + (uint64_t)env, A.step_idx, ic, it, Pn);
+        random_init<true>(A.rc, STREAM_RESET, A.gid0 + (uint64_t)env, A.ctr[tile], ic, it, Pn);
         if (A.randomise >= 2) store_par(A.par, tile, lane, Pn);
     } else {
         nominal_init(ic, it);
@@ -374,6 +390,12 @@ __global__ __launch_bounds__(kBlock) void k_hover_reset(StepArgs A, const uint8_
     const float *src = A.init + env * 13;
     for (int i = 0; i < 13; ++i) { b[(F_SC + i) * kTile] = src[i]; if (A.obs) A.obs[env * 13 + i] = src[i]; }
     for (int i = 0; i < 4; ++i) b[(F_UC + i) * kTile] = 0.0f;
+}
+
+__global__ __launch_bounds__(kBlock) void k_fill_ctr(unsigned long long *ctr, int64_t tiles, unsigned long long k)
+{
+    const int64_t i = (int64_t)blockIdx.x * kBlock + threadIdx.x;
+    if (i < tiles) ctr[i] = k;
 }
 
 __global__ void k_nominal_obs(float *out)
@@ -601,7 +623,7 @@ struct QsEnv {
     bool per_env_params = false;
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    uint64_t step = 0;
+    unsigned long long *d_ctr = nullptr;   // device: step counter, one copy per tile
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     float nominal_obs[12] = {0};
     float *gae_ws = nullptr;    // workspace of the chunked GAE scan
@@ -623,7 +645,8 @@ StepArgs make_args(const QsEnv *e)
     A.par = e->par;
     A.n = e->n;
     A.T = 1;
-    A.step_idx = e->step;
+    A.step_idx = 0;
+    A.ctr = e->d_ctr;
     A.gid0 = e->cfg.env_id_offset;
     A.C.kind = e->cfg.kind == QS_KIND_DOCKING_V2 ? 1 : 0;
     A.C.dt = e->cfg.dt;
@@ -797,6 +820,8 @@ int qs_create(const QsConfig *cfg, QsEnv **out)
         const size_t par_bytes = (size_t)e->tiles * kParWords * kTile * sizeof(float) + 64;  // + scratch for nominal_obs
         HIP_TRY(hipMalloc((void **)&e->st, st_bytes));
         HIP_TRY(hipMalloc((void **)&e->par, par_bytes));
+        HIP_TRY(hipMalloc((void **)&e->d_ctr, (size_t)e->tiles * sizeof(unsigned long long)));
+        HIP_TRY(hipMemsetAsync(e->d_ctr, 0, (size_t)e->tiles * sizeof(unsigned long long), e->stream));
         HIP_TRY(hipMemsetAsync(e->st, 0, st_bytes, e->stream));
         HIP_TRY(hipMemsetAsync(e->par, 0, par_bytes, e->stream));
         int r = fill_params(e);
@@ -839,6 +864,7 @@ int qs_destroy(QsEnv *e)
     if (e->st) (void)hipFree(e->st);
     if (e->par) (void)hipFree(e->par);
     if (e->init) (void)hipFree(e->init);
+    if (e->d_ctr) (void)hipFree(e->d_ctr);
     if (e->gae_ws) (void)hipFree(e->gae_ws);
     if (e->stage) (void)hipFree(e->stage);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
@@ -851,8 +877,9 @@ int qs_destroy(QsEnv *e)
 int qs_set_stream(QsEnv *e, void *hip_stream, int32_t external)
 {
     CHECK_ENV(e);
-    HIP_TRY(hipStreamSynchronize(e->stream));
-    if (e->own_stream) { HIP_TRY(hipStreamDestroy(e->stream)); e->own_stream = false; }
+    // an owned stream is drained and destroyed; switching between caller-owned streams is the caller's ordering
+    // problem (torch does it for stream capture) and must not synchronise
+    if (e->own_stream) { HIP_TRY(hipStreamSynchronize(e->stream)); HIP_TRY(hipStreamDestroy(e->stream)); e->own_stream = false; }
     if (external) e->stream = (hipStream_t)hip_stream;
     else { HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking)); e->own_stream = true; }
     return QS_OK;
@@ -884,15 +911,21 @@ int qs_timer_stop(QsEnv *e, float *ms)
 
 int qs_get_step_counter(QsEnv *e, uint64_t *k)
 {
-    if (!e || !k) return fail(QS_ERR_INVALID, "qs_get_step_counter: null argument");
-    *k = e->step;
+    if (!k) return fail(QS_ERR_INVALID, "qs_get_step_counter: null argument");
+    CHECK_ENV(e);
+    unsigned long long v = 0;
+    HIP_TRY(hipMemcpyAsync(&v, e->d_ctr, sizeof v, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    *k = v;
     return QS_OK;
 }
 
 int qs_set_step_counter(QsEnv *e, uint64_t k)
 {
-    if (!e) return fail(QS_ERR_INVALID, "qs_set_step_counter: null handle");
-    e->step = k;
+    CHECK_ENV(e);
+    hipLaunchKernelGGL(k_fill_ctr, dim3(grid_flat(e->tiles)), dim3(kBlock), 0, e->stream, e->d_ctr, e->tiles, (unsigned long long)k);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(e->stream));
     return QS_OK;
 }
 
@@ -948,7 +981,6 @@ int qs_step(QsEnv *e, const float *actions, float *obs, float *reward, uint8_t *
         if (terminal_obs) HIP_TRY(hipMemcpyAsync(terminal_obs, d_term, n * od * sizeof(float), hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
     }
-    e->step += 1;
     return QS_OK;
 }
 
@@ -983,7 +1015,6 @@ int qs_rollout(QsEnv *e, int64_t T, const float *actions, float *obs, float *rew
         if (flags) HIP_TRY(hipMemcpyAsync(flags, d_flags, tn, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
     }
-    e->step += (uint64_t)T;
     return QS_OK;
 }
 
@@ -996,7 +1027,6 @@ int qs_rollout_stepwise(QsEnv *e, int64_t T, const float *actions, float *obs, f
     const int64_t n = e->n;
     StepArgs A = make_args(e);
     for (int64_t t = 0; t < T; ++t) {
-        A.step_idx = e->step + (uint64_t)t;
         A.actions = actions + t * n * 4;
         A.obs = obs + t * n * e->obs_dim;
         A.reward = reward + t * n;
@@ -1005,7 +1035,6 @@ int qs_rollout_stepwise(QsEnv *e, int64_t T, const float *actions, float *obs, f
         int r = launch_env(e, A);
         if (r) return r;
     }
-    e->step += (uint64_t)T;
     return QS_OK;
 }
 
@@ -1242,7 +1271,6 @@ int qs_policy_rollout(QsEnv *e, int64_t T, const float *wt1, const float *b1, co
     else if (rm == 0) hipLaunchKernelGGL((k_policy_rollout<1, 0>), dim3(grid), dim3(kBlock), 0, e->stream, A, M, actions);
     else hipLaunchKernelGGL((k_policy_rollout<1, 1>), dim3(grid), dim3(kBlock), 0, e->stream, A, M, actions);
     HIP_TRY(hipGetLastError());
-    e->step += (uint64_t)T;
     return QS_OK;
 }
 

@@ -87,10 +87,12 @@ class VecDockingEnv:
         cfg.inertia_scale = (C.c_float * 2)(*inertia_scale)
         cfg.mass = mass
         cfg.inertia = (C.c_float * 3)(*inertia)
+        self._follow_torch_stream = bool(use_torch_stream)
+        self._stream = None
         if use_torch_stream:
-            with torch.cuda.device(self.device):
-                cfg.stream = torch.cuda.current_stream().cuda_stream or None
-                cfg.external_stream = 1
+            self._stream = torch.cuda.current_stream(self.device).cuda_stream
+            cfg.stream = self._stream or None
+            cfg.external_stream = 1
         self.cfg = cfg
         self._h = C.c_void_p()
         _lib.check(self._lib.qs_create(C.byref(cfg), C.byref(self._h)), "qs_create")
@@ -126,6 +128,16 @@ class VecDockingEnv:
     def _out(self, t):
         return t.cpu().numpy() if self.backend == "numpy" else t
 
+    def _use_current_stream(self):
+        """launch on whatever stream torch considers current (it changes under torch.cuda.stream(...) and during
+        torch.cuda.graph capture); a no-op when it has not changed"""
+        if self._follow_torch_stream:
+            raw = getattr(_torch()._C, "_cuda_getCurrentRawStream", None)       # ~0.2 us; the public API costs ~2 us
+            s = raw(self.device_index) if raw is not None else _torch().cuda.current_stream(self.device).cuda_stream
+            if s != self._stream:
+                _lib.check(self._lib.qs_set_stream(self._h, C.c_void_p(s) if s else None, 1), "qs_set_stream")
+                self._stream = s
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             self._lib.qs_destroy(self._h)
@@ -143,6 +155,7 @@ class VecDockingEnv:
     # ------------------------------------------------------------------ VecEnv protocol
     def reset(self, mask=None):
         """DockingEnv.reset for all (or masked) envs -> obs [N,12]"""
+        self._use_current_stream()
         m = None
         if mask is not None:
             m = self._as_device(mask, (self.num_envs,), _torch().uint8)
@@ -150,6 +163,7 @@ class VecDockingEnv:
         return self._out(self._obs.clone() if self.backend == "torch" else self._obs)
 
     def step_async(self, actions):
+        self._use_current_stream()
         self._actions = self._as_device(actions, (self.num_envs, 4))
         _lib.check(self._lib.qs_step(self._h, self._ptr(self._actions), self._ptr(self._obs), self._ptr(self._rew),
                                      self._ptr(self._done), self._ptr(self._flags),
@@ -173,6 +187,7 @@ class VecDockingEnv:
         out: optional (obs, reward, done, flags) tensors to write into.
         -> obs [T,N,12], reward [T,N], done [T,N] (uint8), flags [T,N] or None (torch tensors)."""
         torch = _torch()
+        self._use_current_stream()
         if actions is not None:
             T = int(actions.shape[0])
             actions = self._as_device(actions, (T, self.num_envs, 4))

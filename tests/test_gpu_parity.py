@@ -731,3 +731,55 @@ def test_million_env_batch_matches_small_batch(qa):
     o, r, d, _ = big.step(a)
     assert bool(torch.isfinite(o).all()) and bool(torch.isfinite(r).all())
     big.close(); small.close()
+
+
+def test_step_is_graph_capturable_and_replay_advances_rng(qa):
+    """torch.cuda.graphs capture of a policy-in-the-loop chunk (torch GEMMs + qs_step): the global step counter
+    lives on the device, so every replay draws fresh reset randomness; two replays == the same 2 x K eager steps"""
+    import os, torch
+    from conftest import GOLDEN
+    pol = qa.MlpPolicy.from_npz(os.path.join(GOLDEN, "policy_best_model_v0.npz"))
+    K = 8
+    kw = dict(num_envs=2048, randomise=1, seed=8, init_range=qa.C3_INIT_RANGE)
+    eager = qa.VecDockingEnv("docking-v0", **kw); cap = qa.VecDockingEnv("docking-v0", **kw)
+    t0 = np.zeros(2048, np.float32); t0[::2] = 590.0               # half the envs time out inside the 16 steps
+    for e in (eager, cap):
+        e.reset(); e.set_state(t=t0)
+    # eager reference: 2K steps
+    obs = eager._obs.clone(); eager._use_current_stream()
+    obs.copy_(torch.as_tensor(qa.rel_obs_batch(eager.get_state()["chaser"], eager.get_state()["target"])).cuda())
+    ref = []
+    for _ in range(2 * K):
+        obs, r, d, _ = eager.step(pol.predict(obs))
+        ref.append((obs.clone(), r.clone(), d.clone()))
+    # captured chunk of K steps, replayed twice
+    static_obs = torch.as_tensor(qa.rel_obs_batch(cap.get_state()["chaser"], cap.get_state()["target"])).cuda()
+    outs = [(torch.empty_like(static_obs), torch.empty(2048, device="cuda"), torch.empty(2048, dtype=torch.bool, device="cuda"))
+            for _ in range(K)]
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                                   # warm-up on the side stream (allocator, GEMM plans)
+        o = static_obs.clone()
+        for _ in range(2):
+            pol.predict(o)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    k_before = cap.step_counter
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        o = static_obs
+        for i in range(K):
+            o, r, d, _ = cap.step(pol.predict(o))
+            outs[i][0].copy_(o); outs[i][1].copy_(r); outs[i][2].copy_(d)
+        static_obs.copy_(o)
+    assert cap.step_counter == k_before                              # capture launches nothing
+    n_done = 0
+    for rep in range(2):
+        g.replay()
+        torch.cuda.synchronize()
+        for i in range(K):
+            ro, rr, rd = ref[rep * K + i]
+            assert torch.equal(outs[i][0], ro) and torch.equal(outs[i][1], rr) and torch.equal(outs[i][2], rd), (rep, i)
+            n_done += int(rd.sum())
+    assert n_done >= 1000 and cap.step_counter == k_before + 2 * K
+    eager.close(); cap.close()

@@ -66,6 +66,21 @@ def loop():
 us = timed(loop, 300, 20)
 out["policy_in_the_loop_torch_gemm"] = {"us_per_step": us, "env_steps_per_s": N / us * 1e6,
                                         "mlp_flop_per_env_step": 2 * (12 * 128 + 128 * 128 + 128 * 4)}
+# the same loop captured once with torch.cuda.graphs (the step counter lives on the device: replays stay correct)
+K = 16
+static_obs = state["obs"].clone()
+side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(side):
+    pol.predict(static_obs)
+torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph()
+with torch.cuda.graph(g):
+    o = static_obs
+    for _ in range(K):
+        o, _, _, _ = env.step(pol.predict(o))
+    static_obs.copy_(o)
+us = timed(lambda: g.replay(), 30, 3) / K
+out["policy_in_the_loop_torch_gemm_hipgraph"] = {"us_per_step": us, "env_steps_per_s": N / us * 1e6, "steps_per_graph": K}
 env.close()
 for n in (65536, 262144):
     env = qa.VecDockingEnv("docking-v0", num_envs=n, randomise=1, seed=1, init_range=qa.C3_INIT_RANGE)
