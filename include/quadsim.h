@@ -204,6 +204,15 @@ int qs_policy_rollout(QsEnv *env, int64_t T, const float *wt1, const float *b1, 
                       const float *wt3, const float *b3, float *obs, float *reward, uint8_t *done, uint8_t *flags,
                       float *actions);
 
+/* The same roll-out with the actor on the bf16 matrix rate (16x the f32 MFMA rate) and split operands: each f32
+ * value is carried as bf16 hi + lo and x*w is evaluated as hi*hi + hi*lo + lo*hi with f32 accumulation -- about 1e-5
+ * error on an action instead of float32's 1e-7; opt-in, not bit-compatible with the float32 policy.
+ * packed_weights: device image of qs_policy_rollout_fast_blob_bytes() bytes, 16-byte aligned (layout:
+ * quadsim_amd/csrc/policy_rollout.hpp "Fast actor"; quadsim_amd.policy.pack_fast_weights builds it). */
+int qs_policy_rollout_fast(QsEnv *env, int64_t T, const void *packed_weights, float *obs, float *reward, uint8_t *done,
+                           uint8_t *flags, float *actions);
+int qs_policy_rollout_fast_blob_bytes(void);
+
 /* PID expert of run_expert_policy.py:49-69 / run_expert_record.py:121-136 for all N docking envs: from the handle's
  * current chaser / target states, des_vel = kp (p_target + (-0.2,0,0) - p_chaser) + kd (-v_chaser), vel_controller on
  * the chaser, action = (inv(rotor2control) u - action_mean) / action_std (not clipped).  state_des [N,13] in/out is

@@ -119,4 +119,132 @@ __device__ __forceinline__ void mlp_actor(const float obs[12], float act[4], con
     __builtin_amdgcn_wave_barrier();
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Fast actor: the same MLP on the bf16 matrix rate (16x the f32 MFMA rate) with SPLIT operands.  Every f32 value v
+// is carried as two bf16, hi = bf16(v) and lo = bf16(v - hi), and a product x*w is evaluated as
+// hi*hi + hi*lo + lo*hi with f32 accumulation (three v_mfma_f32_16x16x32_bf16); the dropped lo*lo term and the
+// 16-bit representation leave a relative error of about 2^-17 per product (~1e-5 on an action) instead of f32's
+// 2^-24.  NOT bit-compatible with the float32 policy: an opt-in mode (qs_policy_rollout_fast).
+// Layout: the accumulator-feeds-next-B-operand trick of the f32 path carries over.  A 16x16x32 B operand holds, in
+// element j of lane (g = l>>4, c = l&15), k-slot 8g+j of column c; two accumulator tiles (2p, 2p+1) of the previous
+// layer give that lane exactly 8 values -- hidden index h(p,g,j) = 16(2p + (j>>2)) + 4g + (j&3) -- so k-step p of the
+// next layer sums those 32 hidden units, and the host packs the weights in that order: A fragments are stored
+// ready-made, [tile][k-step][lane][8 bf16], one linear ds_read_b128 per fragment.
+// Packed blob (bytes): A2hi 32768 | A2lo 32768 | A1hi 8192 | A1lo 8192 | A3hi 4096 | A3lo 4096 | b1 512 | b2 512 | b3 64.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+constexpr int kFastBlobBytes = 32768 * 2 + 8192 * 2 + 4096 * 2 + 512 + 512 + 64;
+
+__device__ __forceinline__ void split_bf16(float v, __bf16 &hi, __bf16 &lo)
+{
+    hi = (__bf16)v;
+    lo = (__bf16)(v - (float)hi);
+}
+
+__device__ __forceinline__ void mlp_actor_fast(const float obs[12], float act[4], const char *blob, float *sObs, float *sAct,
+                                               int lane)
+{
+    const bf16x8 *A2hi = reinterpret_cast<const bf16x8 *>(blob);
+    const bf16x8 *A2lo = reinterpret_cast<const bf16x8 *>(blob + 32768);
+    const bf16x8 *A1hi = reinterpret_cast<const bf16x8 *>(blob + 65536);
+    const bf16x8 *A1lo = reinterpret_cast<const bf16x8 *>(blob + 65536 + 8192);
+    const bf16x8 *A3hi = reinterpret_cast<const bf16x8 *>(blob + 65536 + 16384);
+    const bf16x8 *A3lo = reinterpret_cast<const bf16x8 *>(blob + 65536 + 16384 + 4096);
+    const float *sB1 = reinterpret_cast<const float *>(blob + 65536 + 16384 + 8192);
+    const float *sB2 = sB1 + 128;
+    const float *sB3 = sB2 + 128;
+    const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) sObs[k * 64 + lane] = obs[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- layer 1 B operands: k-slot 8g+j = input 8g+j (12 inputs, the rest zero)
+    bf16x8 xh[4], xl[4];
+#pragma unroll
+    for (int et = 0; et < 4; ++et)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = 8 * g + j;                       // g is per lane: guard by value, keep the read in range
+            const float v = (k < 12) ? sObs[(k < 12 ? k : 0) * 64 + 16 * et + c] : 0.0f;
+            __bf16 h, l;
+            split_bf16(v, h, l);
+            xh[et][j] = h; xl[et][j] = l;
+        }
+    // ---- layer 1: 8 row tiles, ReLU, straight into split B operands of layer 2 (tiles 2p, 2p+1 -> k-step p)
+    bf16x8 bh[4][4], bl[4][4];      // [p][et]
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt) {
+        const f32x4 bias = *reinterpret_cast<const f32x4 *>(sB1 + 16 * rt + 4 * g);
+        const bf16x8 ah = A1hi[rt * 64 + lane], al = A1lo[rt * 64 + lane];
+#pragma unroll
+        for (int et = 0; et < 4; ++et) {
+            f32x4 acc = bias;
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh[et], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl[et], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh[et], acc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __bf16 h, l;
+                split_bf16(fmaxf(acc[i], 0.0f), h, l);
+                bh[rt >> 1][et][4 * (rt & 1) + i] = h;
+                bl[rt >> 1][et][4 * (rt & 1) + i] = l;
+            }
+        }
+    }
+    // ---- layer 2 in row-tile pairs, each pair folded into the action accumulators (layer 3 k-step = the pair)
+    f32x4 a3[4];
+    {
+        const f32x4 bias3 = *reinterpret_cast<const f32x4 *>(sB3 + 4 * g);
+#pragma unroll
+        for (int et = 0; et < 4; ++et) a3[et] = bias3;
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                 // q = pair of layer-2 row tiles = k-step of layer 3
+        bf16x8 ch[4], cl[4];                      // split ReLU(H2) of the pair, per env tile
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            const int nt = 2 * q + half;
+            const f32x4 bias = *reinterpret_cast<const f32x4 *>(sB2 + 16 * nt + 4 * g);
+            f32x4 h2[4] = {bias, bias, bias, bias};
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const bf16x8 ah = A2hi[(nt * 4 + p) * 64 + lane], al = A2lo[(nt * 4 + p) * 64 + lane];
+#pragma unroll
+                for (int et = 0; et < 4; ++et) {
+                    h2[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[p][et], h2[et], 0, 0, 0);
+                    h2[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[p][et], h2[et], 0, 0, 0);
+                    h2[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[p][et], h2[et], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int et = 0; et < 4; ++et)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    __bf16 h, l;
+                    split_bf16(fmaxf(h2[et][i], 0.0f), h, l);
+                    ch[et][4 * half + i] = h;
+                    cl[et][4 * half + i] = l;
+                }
+        }
+        const bf16x8 wh = A3hi[q * 64 + lane], wl = A3lo[q * 64 + lane];
+#pragma unroll
+        for (int et = 0; et < 4; ++et) {
+            a3[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ch[et], a3[et], 0, 0, 0);
+            a3[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, cl[et], a3[et], 0, 0, 0);
+            a3[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ch[et], a3[et], 0, 0, 0);
+        }
+    }
+    if (g == 0) {
+#pragma unroll
+        for (int et = 0; et < 4; ++et) *reinterpret_cast<f32x4 *>(sAct + (16 * et + c) * 4) = a3[et];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const f32x4 av = *reinterpret_cast<const f32x4 *>(sAct + lane * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) act[i] = fminf(fmaxf(av[i], -1.0f), 1.0f);
+    __builtin_amdgcn_wave_barrier();
+}
+
 }  // namespace qs

@@ -255,6 +255,48 @@ __global__ __launch_bounds__(kBlock, 1) void k_policy_rollout(StepArgs A, MlpArg
     if (active) { store_env(A.st, tile, lane, e); step_counter_end(A, tile, lane, k0); }
 }
 
+// The same roll-out with the actor on the bf16 matrix rate and split (hi + lo) operands: policy_rollout.hpp,
+// "Fast actor".  `blob` = the host-packed weight image (kFastBlobBytes), copied verbatim into LDS.
+template <int INTEG, int RMODE>
+__global__ __launch_bounds__(kBlock, 1) void k_policy_rollout_fast(StepArgs A, const uint4 *__restrict__ blob, float *__restrict__ actions_out)
+{
+    __shared__ __attribute__((aligned(16))) char lds[kFastBlobBytes + 4 * (12 * 64 + 64 * 4) * 4];
+    for (int i = threadIdx.x; i < kFastBlobBytes / 16; i += kBlock) reinterpret_cast<uint4 *>(lds)[i] = blob[i];
+    __syncthreads();
+    const int lane = threadIdx.x & (kTile - 1);
+    const int w = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x * (kBlock / kTile) + w;
+    const int64_t env = tile * kTile + lane;
+    const bool active = env < A.n;
+    float *stage = reinterpret_cast<float *>(lds + kFastBlobBytes);
+    float *sObs = stage + w * (12 * 64), *sAct = stage + 4 * (12 * 64) + w * (64 * 4);
+    Env e;
+    if (active) load_env(A.st, tile, lane, e);
+    else { nominal_init(e.sc, e.st); for (int i = 0; i < 4; ++i) { e.uc[i] = 0.0f; e.ut[i] = 0.0f; e.qd[i] = i == 0; } e.ls = 0.0f; e.t = 0.0f; }
+    Par P = A.par_nom;
+    const uint64_t k0 = active ? step_counter_begin(A, tile) : 0;
+    float obs[12];
+    rel_obs(e.sc, e.st, obs);
+#pragma clang loop unroll(disable)
+    for (int64_t t = 0; t < A.T; ++t) {
+        float a[4];
+        mlp_actor_fast(obs, a, lds, sObs, sAct, lane);
+        float reward;
+        unsigned flags;
+        bool done;
+        step_and_maybe_reset<INTEG, false, RMODE>(e, P, a, A, active ? env : 0, k0 + (uint64_t)t, obs, reward, flags, done, false);
+        if (active) {
+            const int64_t o = t * A.n + env;
+            store_obs(A.obs, o, obs);
+            A.reward[o] = reward;
+            A.done[o] = done ? 1 : 0;
+            if (A.flags) A.flags[o] = (uint8_t)flags;
+            if (actions_out) reinterpret_cast<float4 *>(actions_out)[o] = make_float4(a[0], a[1], a[2], a[3]);
+        }
+    }
+    if (active) { store_env(A.st, tile, lane, e); step_counter_end(A, tile, lane, k0); }
+}
+
 // hovering-v0 (HoveringEnv.step, hovering_env.py:47-78): T fused steps, one drone per lane.  Uses rows F_SC..
 // (state) and F_UC.. (last limited control) of the tile; obs [T,N,13] = state after the step (or the stored
 // ini_state after an auto-reset, hovering_env.py:80-82).
@@ -1273,6 +1315,32 @@ int qs_policy_rollout(QsEnv *e, int64_t T, const float *wt1, const float *b1, co
     HIP_TRY(hipGetLastError());
     return QS_OK;
 }
+
+int qs_policy_rollout_fast(QsEnv *e, int64_t T, const void *packed_weights, float *obs, float *reward, uint8_t *done,
+                           uint8_t *flags, float *actions)
+{
+    CHECK_ENV(e);
+    if (T < 1 || !packed_weights || !obs || !reward || !done) return fail(QS_ERR_INVALID, "qs_policy_rollout_fast: bad arguments");
+    if (e->cfg.io_space != QS_IO_DEVICE) return fail(QS_ERR_INVALID, "qs_policy_rollout_fast: device buffers only");
+    if (!e->cfg.auto_reset) return fail(QS_ERR_INVALID, "qs_policy_rollout_fast: requires auto_reset");
+    if (e->cfg.kind == QS_KIND_HOVERING_V0 || e->per_env_params || e->init || e->cfg.randomise > 1)
+        return fail(QS_ERR_INVALID, "qs_policy_rollout_fast: docking-v0/v2 with nominal or rocRAND-initialised resets only");
+    if (((uintptr_t)packed_weights & 15) != 0) return fail(QS_ERR_INVALID, "qs_policy_rollout_fast: packed weights must be 16-byte aligned");
+    StepArgs A = make_args(e);
+    A.T = T; A.obs = obs; A.reward = reward; A.done = done; A.flags = flags;
+    const uint4 *blob = (const uint4 *)packed_weights;
+    const unsigned grid = grid_tiles(e->n);
+    const bool fr = e->cfg.integrator == QS_INTEG_FROZEN;
+    const int rm = e->cfg.randomise;
+    if (fr && rm == 0) hipLaunchKernelGGL((k_policy_rollout_fast<0, 0>), dim3(grid), dim3(kBlock), 0, e->stream, A, blob, actions);
+    else if (fr) hipLaunchKernelGGL((k_policy_rollout_fast<0, 1>), dim3(grid), dim3(kBlock), 0, e->stream, A, blob, actions);
+    else if (rm == 0) hipLaunchKernelGGL((k_policy_rollout_fast<1, 0>), dim3(grid), dim3(kBlock), 0, e->stream, A, blob, actions);
+    else hipLaunchKernelGGL((k_policy_rollout_fast<1, 1>), dim3(grid), dim3(kBlock), 0, e->stream, A, blob, actions);
+    HIP_TRY(hipGetLastError());
+    return QS_OK;
+}
+
+int qs_policy_rollout_fast_blob_bytes(void) { return kFastBlobBytes; }
 
 int qs_expert_action(QsEnv *e, float *state_des, float kp, float kd, float *actions)
 {

@@ -32,10 +32,54 @@ class MlpPolicy:
         return t.clamp(t.addmm(self.b2, h, self.w2), -1.0, 1.0)
 
 
-def fused_policy_rollout(env, policy, T, want_actions=True):
-    """The same loop as rollout_with_policy in ONE kernel launch (qs_policy_rollout): MLP on the matrix cores
-    (exact-f32 MFMA) + fused env step, T steps, no host involvement.  Starts from the envs' current state.
-    Returns (obs [T,N,12], reward [T,N], done [T,N] u8, flags [T,N] u8, actions [T,N,4] or None)."""
+def _bf16_bits(x):
+    """float32 -> bfloat16 bit pattern, round to nearest even (what v_cvt_pk_bf16_f32 does)"""
+    u = np.ascontiguousarray(x, np.float32).view(np.uint32)
+    return ((u + (((u >> 16) & 1) + 0x7FFF)) >> 16).astype(np.uint16)
+
+
+def _bf16_to_f32(b):
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+def pack_fast_weights(policy):
+    """Weight image of qs_policy_rollout_fast: every weight split into bf16 hi + lo, A-operand fragments stored
+    ready-made in the k-order the accumulator-as-B-operand chaining needs (csrc/policy_rollout.hpp, 'Fast actor')."""
+    w1t = policy.w0.t().contiguous().cpu().numpy()      # [128][12]
+    w2t = policy.w1.t().contiguous().cpu().numpy()      # [128][128]
+    w3t = policy.w2.t().contiguous().cpu().numpy()      # [4][128]
+    lane = np.arange(64); g, c = lane >> 4, lane & 15
+    j = np.arange(8)
+    hid = lambda p: 16 * (2 * p + (j[None, :] >> 2)) + 4 * g[:, None] + (j[None, :] & 3)       # noqa: E731  [lane][j]
+    a2 = np.zeros((8, 4, 64, 8), np.float32)
+    for nt in range(8):
+        for p in range(4):
+            a2[nt, p] = w2t[(16 * nt + c)[:, None], hid(p)]
+    a1 = np.zeros((8, 64, 8), np.float32)
+    k1 = 8 * g[:, None] + j[None, :]
+    for rt in range(8):
+        a1[rt] = np.where(k1 < 12, w1t[(16 * rt + c)[:, None], np.minimum(k1, 11)], 0.0)
+    a3 = np.zeros((4, 64, 8), np.float32)
+    for q in range(4):
+        a3[q] = np.where((c < 4)[:, None], w3t[np.minimum(c, 3)[:, None], hid(q)], 0.0)
+    parts = []
+    for a in (a2, a1, a3):
+        hi = _bf16_bits(a)
+        lo = _bf16_bits(a - _bf16_to_f32(hi))
+        parts += [hi.tobytes(), lo.tobytes()]
+    b3 = np.zeros(16, np.float32); b3[:4] = policy.b2.cpu().numpy()
+    parts += [policy.b0.cpu().numpy().astype(np.float32).tobytes(), policy.b1.cpu().numpy().astype(np.float32).tobytes(),
+              b3.tobytes()]
+    blob = np.frombuffer(b"".join(parts), np.uint8)
+    return blob
+
+
+def fused_policy_rollout(env, policy, T, want_actions=True, precision="f32"):
+    """The same loop as rollout_with_policy in ONE kernel launch: MLP on the matrix cores + fused env step, T steps,
+    no host involvement.  Starts from the envs' current state.
+    precision "f32": qs_policy_rollout, exact-float32 MFMA (an ordinary float32 network evaluation);
+    precision "bf16x3": qs_policy_rollout_fast, split-bf16 operands on the 16x faster bf16 matrix rate, ~1e-5 error
+    on the actions.  Returns (obs [T,N,12], reward [T,N], done [T,N] u8, flags [T,N] u8, actions [T,N,4] or None)."""
     import ctypes as C
     import torch
     from . import _lib
@@ -49,8 +93,19 @@ def fused_policy_rollout(env, policy, T, want_actions=True):
     flags = torch.empty((T, n), dtype=torch.uint8, device=dev)
     acts = torch.empty((T, n, 4), dtype=torch.float32, device=dev) if want_actions else None
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None      # noqa: E731
-    _lib.check(env._lib.qs_policy_rollout(env._h, T, *[p(w) for w in policy._wt], p(obs), p(rew), p(done), p(flags),
-                                          p(acts)), "qs_policy_rollout")
+    env._use_current_stream()
+    if precision == "bf16x3":
+        if not hasattr(policy, "_blob"):
+            blob = pack_fast_weights(policy)
+            assert blob.size == env._lib.qs_policy_rollout_fast_blob_bytes()
+            policy._blob = torch.as_tensor(blob.copy()).to(dev)
+        _lib.check(env._lib.qs_policy_rollout_fast(env._h, T, p(policy._blob), p(obs), p(rew), p(done), p(flags), p(acts)),
+                   "qs_policy_rollout_fast")
+    elif precision == "f32":
+        _lib.check(env._lib.qs_policy_rollout(env._h, T, *[p(w) for w in policy._wt], p(obs), p(rew), p(done), p(flags),
+                                              p(acts)), "qs_policy_rollout")
+    else:
+        raise ValueError("precision must be 'f32' or 'bf16x3'")
     return obs, rew, done, flags, acts
 
 

@@ -783,3 +783,30 @@ def test_step_is_graph_capturable_and_replay_advances_rng(qa):
             n_done += int(rd.sum())
     assert n_done >= 1000 and cap.step_counter == k_before + 2 * K
     eager.close(); cap.close()
+
+
+def test_fast_policy_rollout_split_bf16(qa):
+    """qs_policy_rollout_fast: split-bf16 (hi + lo) operands on the bf16 matrix rate.  Opt-in precision: its actions
+    stay within 1e-4 of the float32 actor's on identical observations, and the reference episode still docks."""
+    import os
+    from conftest import GOLDEN
+    g = load_golden("g5_policy_episode")
+    pol = qa.MlpPolicy.from_npz(os.path.join(GOLDEN, "policy_best_model_v0.npz"))
+    kw = dict(num_envs=3000, randomise=1, seed=5, init_range=qa.C3_INIT_RANGE)
+    e1 = qa.VecDockingEnv("docking-v0", **kw); e2 = qa.VecDockingEnv("docking-v0", **kw)
+    e1.reset(); e2.reset()
+    O1, R1, D1, F1, A1 = qa.fused_policy_rollout(e1, pol, 1, precision="f32")
+    O2, R2, D2, F2, A2 = qa.fused_policy_rollout(e2, pol, 1, precision="bf16x3")
+    err = float((A1 - A2).abs().max())
+    assert err < 1e-4, err                                     # same observations -> same MLP up to the split error
+    assert err > 0.0                                           # (and it is a different evaluation, not the f32 path)
+    e1.close(); e2.close()
+    env = qa.VecDockingEnv("docking-v0", num_envs=70, auto_reset=True)
+    env.reset()
+    O, R, D, F, A = (x.cpu().numpy() for x in qa.fused_policy_rollout(env, pol, 600, precision="bf16x3"))
+    env.close()
+    assert np.all(O[:, 0] == O[:, 69])
+    np.testing.assert_allclose(A[:, 0], g["actions"], atol=1e-2)
+    np.testing.assert_allclose(O[:599, 0], g["obs"][:599], atol=5e-3)
+    assert abs(int((F[:, 0] & 1).sum()) - 183) <= 4 and D[599, 0] and not D[:599, 0].any()
+    assert abs(float(R[:, 0].sum()) - float(g["reward"].sum())) < 1e-2

@@ -91,5 +91,8 @@ for n in (65536, 262144):
     out["policy_in_the_loop_fused_mfma_N%d" % n] = {"us_per_step": us, "env_steps_per_s": n / us * 1e6,
         "mlp_tflops": n * flop / (us * 1e-6) / 1e12, "mfma_f32_peak_tflops": 157.3,
         "mfma_frac": n * flop / (us * 1e-6) / 1e12 / 157.3}
+    us = timed(lambda: qa.fused_policy_rollout(env, pol, T, want_actions=False, precision="bf16x3"), 5, 2) / T
+    out["policy_in_the_loop_fused_bf16x3_N%d" % n] = {"us_per_step": us, "env_steps_per_s": n / us * 1e6,
+        "note": "split-bf16 (hi+lo) operands on the bf16 matrix rate; ~1e-5 action error (opt-in)"}
     env.close()
 print(json.dumps(out, indent=1))
