@@ -247,6 +247,30 @@ def main():
                                        "hbm_frac": bpe * nb / (msb * 1e-3 / 200) / 1e9 / HBM_PEAK_GBS}
             env_b.close()
             del pool_b
+        # policy in the loop: a = clip(MLP(obs)); env.step(a), T steps per launch, the shipped PPO2
+        # actor (weights fixture) on the matrix cores.  Needs nominal / rocRAND-initialised resets and no per-env params.
+        wpath = os.path.join(ROOT, "tests", "golden", "policy_best_model_v0.npz")
+        if args.randomise <= 1 and os.path.exists(wpath):
+            from quadsim_amd import MlpPolicy, fused_policy_rollout
+            pol = MlpPolicy.from_npz(wpath, device="cuda:%d" % local_rank)
+            Tp = 32
+            flop = 2 * (12 * 128 + 128 * 128 + 128 * 4)
+            for prec, key in (("f32", "policy_rollout_f32_mfma"), ("bf16x3", "policy_rollout_bf16x3_mfma")):
+                fused_policy_rollout(env, pol, Tp, want_actions=False, precision=prec)
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(4):
+                    fused_policy_rollout(env, pol, Tp, want_actions=False, precision=prec)
+                torch.cuda.synchronize()
+                w5 = max_over_ranks(time.perf_counter() - t0)
+                out[key] = {"value": total_envs * Tp * 4 / w5, "unit": "env-steps/s", "T": Tp,
+                            "mlp_tflops": total_envs * Tp * 4 * flop / w5 / 1e12}
+            out["policy_rollout_f32_mfma"]["roofline"] = {
+                "bound": "mfma", "peak": 157.3 * world, "unit": "TFLOP/s",
+                "achieved": out["policy_rollout_f32_mfma"]["mlp_tflops"],
+                "frac": out["policy_rollout_f32_mfma"]["mlp_tflops"] / (157.3 * world),
+                "note": "exact-f32 MFMA (v_mfma_f32_16x16x4_f32); 36 864 MLP flop per env-step"}
+            out["policy_rollout_bf16x3_mfma"]["note"] = "split-bf16 operands, 3 MFMAs per product, ~1e-5 action error (opt-in)"
         if distributed and args.backend == "nccl":
             # BASELINE configs 4/5: RCCL all-gather of the roll-out slabs (obs, reward, done) once per T-step roll-out
             from quadsim_amd.distributed import gather_rollout
