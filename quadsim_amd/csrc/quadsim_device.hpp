@@ -515,29 +515,22 @@ struct Env {
     float sc[13], st[13], uc[4], ut[4], qd[4], ls, t;
 };
 
-// DockingEnv.step (docking_env.py:104-231) / MovingDockingEnv.step (moving_docking_env.py:111-192)
-template <int INTEG>
-__device__ __forceinline__ void env_step(Env &e, const float a[4], const Par &P, const EnvConst &C, float obs[12],
-                                         float &reward, unsigned &flags)
+// chaser command: rotor2control @ (std*a + mean), docking_env.py:115 with :98-99 and quadrotor.py:56-59
+__device__ __forceinline__ void chaser_command(const float a[4], float m, float u_c[4])
 {
-    e.t += 1.0f;                                              // :108
-    // chaser command: rotor2control @ (std*a + mean), :115 with :98-99 and quadrotor.py:56-59
-    float mean = 0.5f * P.m * kG;
+    float mean = 0.5f * m * kG;
     float f0 = fmaf(mean, a[0], mean), f1 = fmaf(mean, a[1], mean);
     float f2 = fmaf(mean, a[2], mean), f3 = fmaf(mean, a[3], mean);
-    float u_c[4], u_t[4];
     u_c[0] = (f0 + f1) + (f2 + f3);
     u_c[1] = kL * (f1 - f3);
     u_c[2] = kL * (f2 - f0);
     u_c[3] = kLambda * ((f0 - f1) + (f2 - f3));
-    // target command from the target state BEFORE stepping, :119 / v2 :126
-    const float pdes[3] = {10.0f, -50.0f, 5.0f};              // :60
-    const float vdes[3] = {C.vdes_x, 0.0f, 0.0f};
-    const float dv[3] = {0.0f, 0.0f, 0.0f};                   // state_last aliases state_now (moving_docking_env.py:117)
-    target_control(C.kind, pdes, vdes, e.qd, 0.0f, e.st, dv, P.m, u_t);
-    bool lim_t = drone_step<INTEG>(e.st, e.ut, u_t, P, C.dt); // :120
-    bool lim_c = drone_step<INTEG>(e.sc, e.uc, u_c, P, C.dt); // :121
-    rel_obs(e.sc, e.st, obs);                                 // :124-127
+}
+
+// flags, shaping reward, done: docking_env.py:130-222 (v2: moving_docking_env.py:137-183)
+__device__ __forceinline__ void score_step(const float obs[12], const float a[4], float zc, float t, float &ls,
+                                           const EnvConst &C, bool lim_c, bool lim_t, float &reward, unsigned &flags)
+{
     float np2 = obs[0] * obs[0] + obs[1] * obs[1] + obs[2] * obs[2];
     float nv2 = obs[3] * obs[3] + obs[4] * obs[4] + obs[5] * obs[5];
     float ne2 = obs[6] * obs[6] + obs[7] * obs[7] + obs[8] * obs[8];
@@ -546,14 +539,33 @@ __device__ __forceinline__ void env_step(Env &e, const float a[4], const Par &P,
     float np_ = q_sqrt(np2), nv = q_sqrt(nv2), ne = q_sqrt(ne2), nr = q_sqrt(nr2), na = q_sqrt(na2);
     bool docked = (np_ < 0.1f) && (nv < 0.1f) && (fabsf(obs[6]) < kLim10) && (fabsf(obs[7]) < kLim10)
                   && (fabsf(obs[8]) < kLim10);                // :130-134
-    bool over = (np_ >= C.rmax) || (e.sc[2] <= 0.1f);         // :141-142
-    bool overtime = e.t >= kTMax;                             // :152
+    bool over = (np_ >= C.rmax) || (zc <= 0.1f);              // :141-142
+    bool overtime = t >= kTMax;                               // :152
     // shaping, :215-219 / v2 :176-180
     float shaping = -10.0f * np_ * q_rcp(C.rmax) - nv - (10.0f / kPi) * ne - nr - 0.1f * na + (docked ? 1.0f : 0.0f);
-    reward = shaping - e.ls;                                  // :221
-    e.ls = shaping;                                           // :222
+    reward = shaping - ls;                                    // :221
+    ls = shaping;                                             // :222
     flags = (docked ? FLAG_DOCKED : 0u) | (over ? FLAG_OVERLIMIT : 0u) | (overtime ? FLAG_OVERTIME : 0u)
             | (lim_c ? FLAG_CLIM : 0u) | (lim_t ? FLAG_TLIM : 0u);
+}
+
+// DockingEnv.step (docking_env.py:104-231) / MovingDockingEnv.step (moving_docking_env.py:111-192)
+template <int INTEG>
+__device__ __forceinline__ void env_step(Env &e, const float a[4], const Par &P, const EnvConst &C, float obs[12],
+                                         float &reward, unsigned &flags)
+{
+    e.t += 1.0f;                                              // :108
+    float u_c[4], u_t[4];
+    chaser_command(a, P.m, u_c);                              // :115
+    // target command from the target state BEFORE stepping, :119 / v2 :126
+    const float pdes[3] = {10.0f, -50.0f, 5.0f};              // :60
+    const float vdes[3] = {C.vdes_x, 0.0f, 0.0f};
+    const float dv[3] = {0.0f, 0.0f, 0.0f};                   // state_last aliases state_now (moving_docking_env.py:117)
+    target_control(C.kind, pdes, vdes, e.qd, 0.0f, e.st, dv, P.m, u_t);
+    bool lim_t = drone_step<INTEG>(e.st, e.ut, u_t, P, C.dt); // :120
+    bool lim_c = drone_step<INTEG>(e.sc, e.uc, u_c, P, C.dt); // :121
+    rel_obs(e.sc, e.st, obs);                                 // :124-127
+    score_step(obs, a, e.sc[2], e.t, e.ls, C, lim_c, lim_t, reward, flags);
 }
 
 // DockingEnv.reset (docking_env.py:233-244) + Drone.reset (quadrotor.py:65-78):
