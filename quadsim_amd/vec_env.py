@@ -116,6 +116,9 @@ class VecDockingEnv:
     def _as_device(self, x, shape, dtype=None):
         torch = _torch()
         dtype = dtype or torch.float32
+        if (isinstance(x, torch.Tensor) and x.dtype == dtype and x.device == self.device and x.is_contiguous()
+                and tuple(x.shape) == tuple(shape)):
+            return x                                   # the per-step fast path: nothing to convert
         if isinstance(x, torch.Tensor):
             t = x.to(device=self.device, dtype=dtype)
         else:
@@ -171,7 +174,8 @@ class VecDockingEnv:
 
     def step_wait(self):
         if self.backend == "torch":
-            return self._obs, self._rew, self._done.bool(), InfoView(self)
+            # views of the env's own buffers (valid until the next step); done is the uint8 buffer seen as bool
+            return self._obs, self._rew, self._done.view(_torch().bool), InfoView(self)
         obs, rew = self._obs.cpu().numpy(), self._rew.cpu().numpy()
         done, flags = self._done.cpu().numpy().astype(bool), self._flags.cpu().numpy()
         infos = InfoView(self, done=done, flags=flags)
