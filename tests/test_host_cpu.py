@@ -154,3 +154,34 @@ dist.destroy_process_group()
     outs = [p.communicate(timeout=240)[0] for p in procs]
     assert all(p.returncode == 0 for p in procs), "\n".join(outs)
     assert "OK" in outs[0]
+
+
+def test_gym_id_registration_with_stub_gym(monkeypatch):
+    """gym-docking/gym_docking/__init__.py:3-17 registers docking-v0/v1/v2 and hovering-v0; with a gym importable
+    the same ids resolve to the HIP-backed classes (gym itself is absent on the build image: stub namespace)"""
+    import types
+    calls = []
+    gym = types.ModuleType("gym"); envs = types.ModuleType("gym.envs"); reg = types.ModuleType("gym.envs.registration")
+    reg.register = lambda id, entry_point, **kw: calls.append((id, entry_point))
+    gym.envs = envs; envs.registration = reg
+    for name, mod in (("gym", gym), ("gym.envs", envs), ("gym.envs.registration", reg)):
+        monkeypatch.setitem(sys.modules, name, mod)
+    from quadsim_amd.envs import register_gym_ids
+    assert register_gym_ids() is True
+    ids = dict(calls)
+    assert ids["docking-v0"] == "quadsim_amd.envs:DockingEnv" and ids["docking-v2"] == "quadsim_amd.envs:MovingDockingEnv"
+    assert ids["docking-v1"] == "quadsim_amd.envs:ImitatingDockingEnv" and ids["hovering-v0"] == "quadsim_amd.envs:HoveringEnv"
+    import quadsim_amd.envs as E
+    for _, ep in calls:
+        assert hasattr(E, ep.split(":")[1])
+
+
+def test_vecenv_and_gym_method_surface():
+    """the duck-typed protocols the reference's callers use: SB2 VecEnv (rl_baselines/ppo2/ppo2.py:472-499) and old-gym Env"""
+    import quadsim_amd as qa
+    for m in ("reset", "step_async", "step_wait", "step", "close", "get_attr", "set_attr", "env_method", "seed", "render"):
+        assert callable(getattr(qa.VecDockingEnv, m)), m
+    for cls in (qa.DockingEnv, qa.MovingDockingEnv, qa.ImitatingDockingEnv, qa.HoveringEnv):
+        for m in ("reset", "step", "seed", "render", "close"):
+            assert callable(getattr(cls, m)), (cls, m)
+    assert qa.make.__doc__ and qa.shard_range(8, 0, 2) == (0, 4)
