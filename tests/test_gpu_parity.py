@@ -810,3 +810,37 @@ def test_fast_policy_rollout_split_bf16(qa):
     np.testing.assert_allclose(O[:599, 0], g["obs"][:599], atol=5e-3)
     assert abs(int((F[:, 0] & 1).sum()) - 183) <= 4 and D[599, 0] and not D[:599, 0].any()
     assert abs(float(R[:, 0].sum()) - float(g["reward"].sum())) < 1e-2
+
+
+def test_integration_md_stub_runs(qa, monkeypatch):
+    """the reference-side ctypes binding printed in INTEGRATION.md section 2 is executable as written (with a stub gym
+    namespace, gym being absent here) and reproduces the first steps of the reference trajectory"""
+    import os, re, sys, types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(.*?)```", text, flags=re.S).group(1)
+    from quadsim_amd import _lib
+    code = code.replace('C.CDLL("libquadsim_hip.so")', 'C.CDLL(%r)' % _lib.LIB_PATH)
+    gym = types.ModuleType("gym"); spaces = types.ModuleType("gym.spaces")
+
+    class Env:
+        pass
+
+    class Box:
+        def __init__(self, low, high, dtype=None):
+            self.low, self.high, self.shape = np.asarray(low), np.asarray(high), np.asarray(low).shape
+
+    gym.Env, spaces.Box, gym.spaces = Env, Box, spaces
+    monkeypatch.setitem(sys.modules, "gym", gym); monkeypatch.setitem(sys.modules, "gym.spaces", spaces)
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    env = ns["HipDockingEnv"]()
+    g = load_golden("g4_traj_v0")
+    np.testing.assert_allclose(env.reset(), g["first_obs"], atol=2e-6)
+    for t in range(30):
+        obs, r, d, info = env.step(g["actions"][t])
+        np.testing.assert_allclose(obs, g["obs"][t], rtol=1e-4, atol=1e-4)
+        assert abs(r - g["reward"][t]) < 1e-3 and d == bool(g["done"][t])
+        assert set(info) == {"chaser", "target", "flag_docking", "done_overlimit"}
+    assert env.action_space.shape == (4,) and env.observation_space.shape == (12,)
+    env.close()
