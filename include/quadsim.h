@@ -171,7 +171,9 @@ int qs_obs_dim(QsEnv *env, int32_t *dim);
 int qs_set_params(QsEnv *env, const float *mass, const float *inertia);
 int qs_get_params(QsEnv *env, float *mass, float *inertia);
 
-/* global step counter k (number of qs_step calls / rollout steps so far); keys the RNG streams */
+/* global step counter k (number of env steps executed so far); keys the RNG streams.  It lives in device memory
+ * and is advanced by the step kernels themselves, so a launch captured in a hipGraph advances it on every replay;
+ * reading it synchronises the handle's stream. */
 int qs_get_step_counter(QsEnv *env, uint64_t *k);
 int qs_set_step_counter(QsEnv *env, uint64_t k);
 
