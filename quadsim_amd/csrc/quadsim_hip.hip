@@ -170,6 +170,10 @@ __global__ __launch_bounds__(kBlock) void k_env(StepArgs A)
     const int64_t env = tile * kTile + lane;
     if (env >= A.n) return;
     const uint64_t k0 = step_counter_begin(A, tile);
+    // the first action is requested together with the tile (one exposed memory latency per launch, not two) and
+    // every later one a whole step ahead of its use
+    float4 av_next = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    if (A.actions) av_next = reinterpret_cast<const float4 *>(A.actions)[env];
     Env e;
     load_env(A.st, tile, lane, e);
     Par P = A.par_nom;
@@ -180,7 +184,8 @@ __global__ __launch_bounds__(kBlock) void k_env(StepArgs A)
         const int64_t o = t * A.n + env;
         float a[4];
         if (A.actions) {
-            const float4 av = reinterpret_cast<const float4 *>(A.actions)[o];
+            const float4 av = av_next;
+            if (t + 1 < A.T) av_next = reinterpret_cast<const float4 *>(A.actions)[o + A.n];
             a[0] = av.x; a[1] = av.y; a[2] = av.z; a[3] = av.w;
         } else {
             random_action(A.rc.seed, A.gid0 + (uint64_t)env, k, a);
