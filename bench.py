@@ -273,19 +273,19 @@ def main():
             out["policy_rollout_bf16x3_mfma"]["note"] = "split-bf16 operands, 3 MFMAs per product, ~1e-5 action error (opt-in)"
         if distributed and args.backend == "nccl":
             # BASELINE configs 4/5: RCCL all-gather of the roll-out slabs (obs, reward, done) once per T-step roll-out
-            from quadsim_amd.distributed import gather_rollout
-            o_, r_, d_, _f = env.rollout(acts, want_flags=False)
-            gathered = gather_rollout(o_, r_, d_)
+            from quadsim_amd.distributed import gather_slab
+            slab = env.rollout_slab(acts)
+            gathered = gather_slab(slab)
             barrier()
             t0 = time.perf_counter()
             for _ in range(reps):
-                o_, r_, d_, _f = env.rollout(acts, want_flags=False)
-                gather_rollout(o_, r_, d_, out=gathered)
+                env.rollout_slab(acts, out=slab)
+                gather_slab(slab, out=gathered)
             torch.cuda.synchronize()
             w4 = max_over_ranks(time.perf_counter() - t0)
             out["allgather"] = {"value": total_envs * T * reps / w4, "unit": "env-steps/s",
-                                "what": "qs_rollout(T=%d) + RCCL all_gather of obs/reward/done slabs (%.1f MB per rank "
-                                        "per roll-out)" % (T, T * n * 53 / 1e6)}
+                                "what": "qs_rollout_slab(T=%d) + ONE RCCL all_gather of the packed (obs, reward, done) slab "
+                                        "(%.1f MB per rank per roll-out)" % (T, T * n * 56 / 1e6)}
 
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(kind, args.cpu_seconds)

@@ -135,6 +135,11 @@ int qs_step(QsEnv *env, const float *actions, float *obs, float *reward, uint8_t
 int qs_rollout(QsEnv *env, int64_t T, const float *actions, float *obs, float *reward, uint8_t *done,
                uint8_t *flags);
 
+/* qs_rollout writing ONE packed slab [T,N,14] float32 = obs 12, reward, done (0.0 / 1.0) per env-step: the 56-byte
+ * unit BASELINE configs 4/5 all-gather over xGMI (one large collective per roll-out instead of three).  actions
+ * [T,N,4] or NULL (in-kernel U(-1,1)); flags [T,N] nullable.  Same values as qs_rollout.  Docking envs. */
+int qs_rollout_slab(QsEnv *env, int64_t T, const float *actions, float *slab, uint8_t *flags);
+
 /* Same contract and bit-identical results as qs_rollout, but issued as T single-step launches from
  * native code (what a per-step trainer loop costs the GPU, without the interpreter between launches).
  * actions [T,N,4] required. */

@@ -23,7 +23,7 @@ FLAG_DOCKED, FLAG_OVERLIMIT, FLAG_OVERTIME, FLAG_CHASER_LIMITED, FLAG_TARGET_LIM
 
 EXPORTS = [
     "qs_config_default", "qs_version", "qs_last_error", "qs_create", "qs_destroy", "qs_reset", "qs_step",
-    "qs_rollout", "qs_rollout_stepwise", "qs_fill_random_actions", "qs_get_state", "qs_set_state", "qs_set_params", "qs_get_params",
+    "qs_rollout", "qs_rollout_slab", "qs_rollout_stepwise", "qs_fill_random_actions", "qs_get_state", "qs_set_state", "qs_set_params", "qs_get_params",
     "qs_set_init_state", "qs_get_init_state", "qs_obs_dim", "qs_get_step_counter", "qs_set_step_counter", "qs_set_stream", "qs_sync", "qs_timer_start", "qs_timer_stop",
     "qs_drone_step", "qs_ctrl", "qs_rel_obs", "qs_transform", "qs_gae", "qs_swap_and_flatten", "qs_expert_action", "qs_policy_rollout", "qs_policy_rollout_fast", "qs_policy_rollout_fast_blob_bytes",
 ]
@@ -94,6 +94,7 @@ def load():
         "qs_step": [vp, vp, vp, vp, vp, vp, vp],
         "qs_rollout": [vp, i64, vp, vp, vp, vp, vp],
         "qs_rollout_stepwise": [vp, i64, vp, vp, vp, vp, vp],
+        "qs_rollout_slab": [vp, i64, vp, vp, vp],
         "qs_fill_random_actions": [vp, i64, u64, vp],
         "qs_get_state": [vp] + [vp] * 6,
         "qs_set_state": [vp] + [vp] * 6,

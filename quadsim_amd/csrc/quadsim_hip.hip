@@ -41,6 +41,7 @@ struct StepArgs {
     uint8_t *done;
     uint8_t *flags;        // nullable
     float *term_obs;       // nullable, [N,12] (T == 1 only)
+    float *slab;           // nullable: packed roll-out slab [T,N,14] = obs 12, reward, done (as 0/1); replaces obs/reward/done
     int64_t n;
     int64_t T;             // rollout length (1 for step)
     uint64_t step_idx;     // explicit step index (k_fill_actions); the env kernels read the device counter below
@@ -194,9 +195,17 @@ __global__ __launch_bounds__(kBlock) void k_env(StepArgs A)
         unsigned flags;
         bool done;
         step_and_maybe_reset<INTEG, PARAMS, RMODE>(e, P, a, A, env, k, obs, reward, flags, done, true);
-        store_obs(A.obs, o, obs);
-        A.reward[o] = reward;
-        A.done[o] = done ? 1 : 0;
+        if (A.slab) {
+            // one 56-byte row per env-step (the unit the multi-GPU all-gather moves): seven 8-byte stores
+            float2 *row = reinterpret_cast<float2 *>(A.slab + o * 14);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) row[i] = make_float2(obs[2 * i], obs[2 * i + 1]);
+            row[6] = make_float2(reward, done ? 1.0f : 0.0f);
+        } else {
+            store_obs(A.obs, o, obs);
+            A.reward[o] = reward;
+            A.done[o] = done ? 1 : 0;
+        }
         if (A.flags) A.flags[o] = (uint8_t)flags;
     }
     store_env(A.st, tile, lane, e);
@@ -1063,6 +1072,18 @@ int qs_rollout(QsEnv *e, int64_t T, const float *actions, float *obs, float *rew
         HIP_TRY(hipStreamSynchronize(e->stream));
     }
     return QS_OK;
+}
+
+int qs_rollout_slab(QsEnv *e, int64_t T, const float *actions, float *slab, uint8_t *flags)
+{
+    CHECK_ENV(e);
+    if (T < 1 || !slab) return fail(QS_ERR_INVALID, "qs_rollout_slab: bad arguments");
+    if (!e->cfg.auto_reset) return fail(QS_ERR_INVALID, "qs_rollout_slab: requires auto_reset");
+    if (e->cfg.io_space != QS_IO_DEVICE) return fail(QS_ERR_INVALID, "qs_rollout_slab: device buffers only");
+    if (e->cfg.kind == QS_KIND_HOVERING_V0) return fail(QS_ERR_INVALID, "qs_rollout_slab: docking envs only");
+    StepArgs A = make_args(e);
+    A.T = T; A.actions = actions; A.slab = slab; A.flags = flags;
+    return launch_env(e, A);
 }
 
 int qs_rollout_stepwise(QsEnv *e, int64_t T, const float *actions, float *obs, float *reward, uint8_t *done, uint8_t *flags)

@@ -210,6 +210,19 @@ class VecDockingEnv:
                       self._ptr(flags)), "qs_rollout")
         return obs, rew, done, flags
 
+    def rollout_slab(self, actions=None, T=None, out=None):
+        """qs_rollout_slab: T fused steps written as one packed slab [T,N,14] (obs 12, reward, done as 0/1)."""
+        torch = _torch()
+        self._use_current_stream()
+        if actions is not None:
+            T = int(actions.shape[0])
+            actions = self._as_device(actions, (T, self.num_envs, 4))
+        elif T is None:
+            raise ValueError("give actions or T")
+        slab = out if out is not None else torch.empty((T, self.num_envs, 14), dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.qs_rollout_slab(self._h, T, self._ptr(actions), self._ptr(slab), None), "qs_rollout_slab")
+        return slab
+
     def random_actions(self, T, step0=None):
         """[T,N,4] synthetic U(-1,1) actions from the rocRAND action stream"""
         torch = _torch()

@@ -844,3 +844,23 @@ def test_integration_md_stub_runs(qa, monkeypatch):
         assert set(info) == {"chaser", "target", "flag_docking", "done_overlimit"}
     assert env.action_space.shape == (4,) and env.observation_space.shape == (12,)
     env.close()
+
+
+def test_rollout_slab_equals_rollout(qa):
+    """the packed [T,N,14] slab (the all-gather unit of BASELINE configs 4/5) holds exactly qs_rollout's obs / reward / done"""
+    from quadsim_amd.distributed import split_slab
+    kw = dict(num_envs=777, randomise=2, seed=12, init_range=qa.C3_INIT_RANGE, mass_scale=(0.8, 1.2), inertia_scale=(0.8, 1.2))
+    e1 = qa.VecDockingEnv("docking-v2", **kw); e2 = qa.VecDockingEnv("docking-v2", **kw)
+    t0 = np.zeros(777, np.float32); t0[::4] = 590.0
+    for e in (e1, e2):
+        e.reset(); e.set_state(t=t0)
+    acts = e1.random_actions(24)
+    O, R, D, F = e1.rollout(acts)
+    slab = e2.rollout_slab(acts)
+    o, r, d = split_slab(slab)
+    assert np.array_equal(o.cpu().numpy(), O.cpu().numpy()) and np.array_equal(r.cpu().numpy(), R.cpu().numpy())
+    assert np.array_equal(d.cpu().numpy(), D.cpu().numpy().astype(bool)) and int(D.sum()) > 100
+    s1, s2 = e1.get_state(), e2.get_state()
+    for k in s1:
+        assert np.array_equal(s1[k], s2[k])
+    e1.close(); e2.close()

@@ -117,7 +117,7 @@ import os, sys
 import numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, %r)
 from oracle.pyoracle import Oracle, PAR_NOMINAL
-from quadsim_amd.distributed import env_shard, gather_rollout, rollout_global_view
+from quadsim_amd.distributed import env_shard, gather_rollout, gather_slab, rollout_global_view, split_slab
 
 dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
 rank, world = dist.get_rank(), dist.get_world_size()
@@ -142,6 +142,12 @@ if rank == 0:
     assert np.array_equal(rollout_global_view(R).numpy(), r1)
     assert np.array_equal(rollout_global_view(D).numpy(), d1)
     assert d1.sum() >= N
+    # the packed-slab path: one collective
+slab = torch.from_numpy(np.concatenate([o, r[..., None], d[..., None].astype(np.float32)], axis=-1).astype(np.float32))
+S = gather_slab(slab)
+if rank == 0:
+    so, sr, sd = split_slab(rollout_global_view(S))
+    assert np.array_equal(so.numpy(), o1) and np.array_equal(sr.numpy(), r1) and np.array_equal(sd.numpy(), d1.astype(bool))
     print("OK")
 dist.destroy_process_group()
 ''' % ROOT)
