@@ -244,10 +244,14 @@ void FN(qso_u_limit)(const real u[4], const real par[4], real out[4])
     real p1 = (real)0.25 * u[0] + a * u[1];
     real p2 = (real)0.25 * u[0] + a * u[2];
     real p3 = (real)0.25 * u[0] + (-a) * u[1];
-    if (p0 > hi) p0 = hi; if (p0 < lo) p0 = lo;
-    if (p1 > hi) p1 = hi; if (p1 < lo) p1 = lo;
-    if (p2 > hi) p2 = hi; if (p2 < lo) p2 = lo;
-    if (p3 > hi) p3 = hi; if (p3 < lo) p3 = lo;
+    if (p0 > hi) p0 = hi;
+    if (p0 < lo) p0 = lo;
+    if (p1 > hi) p1 = hi;
+    if (p1 < lo) p1 = lo;
+    if (p2 > hi) p2 = hi;
+    if (p2 < lo) p2 = lo;
+    if (p3 > hi) p3 = hi;
+    if (p3 < lo) p3 = lo;
     out[0] = p0 + p1 + p2 + p3;                               /* :182 */
     out[1] = K_L * p1 - K_L * p3;                             /* :185 row 1 of B */
     out[2] = -K_L * p0 + K_L * p2;                            /* :185 row 2 of B */
