@@ -864,3 +864,68 @@ def test_rollout_slab_equals_rollout(qa):
     for k in s1:
         assert np.array_equal(s1[k], s2[k])
     e1.close(); e2.close()
+
+
+@pytest.mark.parametrize("env_id,kind", [("docking-v0", 0), ("docking-v2", 1)])
+def test_env_step_adversarial_states_vs_oracle(qa, env_id, kind):
+    """one fused step from 6 000 adversarial env states (attitudes up to and beyond the limiter thresholds, large rates
+    and stored controls, un-normalised quaternions): the limiter branches, the saturated rot2euler branches and the
+    rotor clamps inside the fused kernel, against the f64 oracle from identical inputs"""
+    import os
+    n = 6000
+    rs = np.random.RandomState(77 + kind)
+    orc = Oracle("f64")
+    def rand_drone(center):
+        s = np.zeros((n, 13))
+        s[:, 0:3] = center + rs.normal(0, 0.8, (n, 3))
+        s[:, 3:6] = rs.normal(0, 1.5, (n, 3))
+        e = rs.uniform(-1, 1, (n, 3)) * np.array([1.7, 1.7, 3.3])
+        q = np.array([orc.euler2quat(x) for x in e])
+        s[:, 6:10] = q * rs.uniform(0.95, 1.05, (n, 1))
+        s[:, 10:13] = rs.normal(0, 3.0, (n, 3))
+        return s
+    sc, st = rand_drone(np.array([8, -50, 5.0])), rand_drone(np.array([10, -50, 5.0]))
+    up = np.concatenate([rs.uniform(0, 7, (n, 1)), rs.normal(0, 5, (n, 3)), rs.uniform(0, 7, (n, 1)), rs.normal(0, 5, (n, 3))], 1)
+    qd = np.array([orc.euler2quat(x) for x in rs.uniform(-0.4, 0.4, (n, 3)) * np.array([1, 1, 7])])
+    ls = rs.uniform(-10, 0, n); t = rs.randint(0, 599, n).astype(np.float64)
+    a = rs.uniform(-1, 1, (n, 4)).astype(np.float32)
+    env = qa.VecDockingEnv(env_id, num_envs=n, auto_reset=False)
+    env.set_state(chaser=sc, target=st, u_prev=up, qdes=qd, last_shaping=ls, t=t)
+    st32 = env.get_state()                                    # the f32-rounded inputs the kernel really sees
+    rec = state_to_rec(st32)
+    obs, rew, done, infos = env.step(a)
+    obs, rew, done, flags = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy(), infos.flags
+    rec2 = state_to_rec(env.get_state())
+    env.close()
+    par = tile_par(n)
+    o, r, d, f, _ = orc.vec_step(rec, par, a, kind=kind, auto_reset=False)
+    # knife-edges: a limiter decision that differs marks a state within fp32 rounding of the 85/175-degree thresholds
+    same_lim = (flags & 24) == (f & 24)
+    assert same_lim.mean() > 0.995
+    fired = int(((f & 24) != 0).sum())
+    assert fired > 1500                                        # the limiter really is exercised
+    ok = same_lim & (threshold_margin(o, rec[:, 2], rec[:, 39], 3.0 if kind == 0 else 10.0) > 1e-4)
+    # gimbal neighbourhood of the relative attitude: tan/sec amplify rounding without bound -> compare rates only away from it
+    gimbal = np.abs(np.abs(o[:, 6]) - np.pi / 2) < 0.05
+    # The target's stored yaw moment, field 33 = -9.5 (psi_des - psi_now) + 4 (0 - r), inherits the conditioning of
+    # psi = atan2(-r10, r11): near the Z-X-Y gimbal (|r12| -> 1) both arguments shrink like cos(phi) and any rounding
+    # of the O(1) products they are formed from is amplified by 1 / hypot(r10, r11).  Its tolerance carries that factor
+    # (current target attitude and the freshly written desired attitude); every other field keeps the flat 1e-5.
+    def yaw_cond(q):
+        w, x, y, z = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+        h = np.hypot(2 * (x * y - w * z), w * w - x * x + y * y - z * z) / (w * w + x * x + y * y + z * z)
+        return 1.0 / np.maximum(h, 1e-4)
+    cond = yaw_cond(st32["target"][:, 6:10].astype(np.float64)) + yaw_cond(rec[:, 34:38])
+    cols = [j for j in range(38) if j != 33]
+    np.testing.assert_allclose(rec2[ok][:, cols], rec[ok][:, cols], **STATE_TOL)
+    assert np.all(np.abs(rec2[ok, 33] - rec[ok, 33]) <= 1e-5 * (1 + np.abs(rec[ok, 33])) + 9.5 * 2e-6 * cond[ok])
+    assert np.median(cond) < 5                                   # the factor matters for the adversarial tail only
+    np.testing.assert_allclose(obs[ok][:, :6], o[ok][:, :6], **OBS_TOL)
+    sat = np.abs(o[:, 6]) == np.pi / 2
+    near = gimbal & ~sat
+    np.testing.assert_allclose(obs[ok & ~near][:, 6:9], o[ok & ~near][:, 6:9], rtol=1e-5, atol=3e-5)
+    far = ok & ~gimbal
+    scale = 1.0 + np.abs(o[far, 9:])
+    assert np.all(np.abs(obs[far, 9:] - o[far, 9:]) <= 1e-4 * scale * (1 + np.abs(np.tan(o[far, 6]))[:, None]))
+    assert np.array_equal(done[ok], d[ok].astype(bool))
+    assert sat.sum() > 100 and far.sum() > 3000
