@@ -271,6 +271,24 @@ def main():
                 "frac": out["policy_rollout_f32_mfma"]["mlp_tflops"] / (157.3 * world),
                 "note": "exact-f32 MFMA (v_mfma_f32_16x16x4_f32); 36 864 MLP flop per env-step"}
             out["policy_rollout_bf16x3_mfma"]["note"] = "split-bf16 operands, 3 MFMAs per product, ~1e-5 action error (opt-in)"
+            # PPO2 data collection (Runner._run, rl_baselines/ppo2/ppo2.py:472-527): actor + critic + Gaussian sampling +
+            # neglogp + env.step for n_steps in one launch, then the GAE kernel and the env-major flatten of 7 arrays
+            from quadsim_amd import ActorCriticPolicy, Runner
+            ac = ActorCriticPolicy.from_npz(wpath, device="cuda:%d" % local_rank)
+            runner = Runner(env=env, model=ac, n_steps=Tp, gamma=0.99, lam=0.95, collect_ep_infos=False)
+            runner.run()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                runner.run()
+            torch.cuda.synchronize()
+            w6 = max_over_ranks(time.perf_counter() - t0)
+            flop_ac = 2 * (12 * 128 + 2 * 128 * 128 + 128 * 4 + 128)
+            out["ppo2_runner_f32_mfma"] = {
+                "value": total_envs * Tp * 4 / w6, "unit": "env-steps/s", "T": Tp,
+                "mlp_tflops": total_envs * (Tp + 1) * 4 * flop_ac / w6 / 1e12,
+                "what": "Runner.run(): qs_runner_rollout (policy + value nets on exact-f32 MFMA, rocRAND Gaussian sampling, "
+                        "neglogp, fused env.step) + qs_gae + swap_and_flatten of obs/returns/dones/actions/values/neglogp/rewards"}
         if distributed and args.backend == "nccl":
             # BASELINE configs 4/5: RCCL all-gather of the roll-out slabs (obs, reward, done) once per T-step roll-out
             from quadsim_amd.distributed import gather_slab

@@ -220,6 +220,38 @@ int qs_policy_rollout_fast(QsEnv *env, int64_t T, const void *packed_weights, fl
                            uint8_t *flags, float *actions);
 int qs_policy_rollout_fast_blob_bytes(void);
 
+/* PPO2 data collection in ONE launch: Runner._run's loop, rl_baselines/ppo2/ppo2.py:472-499, plus last_values (:506),
+ * for the N envs of the handle and T = n_steps, with the actor-critic MlpPolicy the reference trains and ships
+ * (trained_model/best_model_v0.zip; rl_baselines/common/policies.py:35-92,:583-588): shared_fc0 12->128, then
+ * pi_fc0 128->128 -> pi 128->4 (action mean) and vf_fc0 128->128 -> vf 128->1 (value), ReLU, state-independent logstd.
+ * Per step t (model.step, policies.py:592-603 without the fork's tanh unless `squash`):
+ *   mb_obs[t] = obs_t;  mean, value = net(obs_t);  u = mean + exp(logstd) * eps_t   (distributions.py:426-430)
+ *   mb_neglogp[t] = 0.5 sum(((u - mean) / std)^2) + 0.5 log(2 pi) 4 + sum(logstd)    (distributions.py:406-410)
+ *   mb_actions[t] = u;  mb_values[t] = value;  mb_dones[t] = done flags BEFORE the step (ppo2.py:479)
+ *   obs_{t+1}, mb_rewards[t], done = env.step(clip(u, -1, 1))                         (ppo2.py:480-484)
+ * and after the loop last_obs = obs_T, last_values = value(obs_T), last_dones = the final done flags -- exactly the
+ * inputs of qs_gae.  eps_t: `noise` [T,N,4] when given (what tf.random_normal would have drawn), else four standard
+ * normals per env-step from rocRAND Philox4x32-10 (stream 4, subsequence = global env id, block = global step index)
+ * through Box-Muller.  squash != 0 selects the fork's tanh variant (policies.py:238-242, distributions.py:412-415):
+ * the env receives tanh(u), mb_neglogp adds sum(log(1 - tanh(u)^2 + 1e-6)), mb_actions keeps u.
+ * Weights are TRANSPOSED (out, in) row-major float32 DEVICE arrays; logstd is read on the HOST.  The networks run on
+ * the matrix cores in exact float32 (v_mfma_f32_16x16x4_f32).  docking-v0/v2, auto_reset, randomise 0/1, device I/O. */
+typedef struct QsActorCritic {
+    uint32_t struct_size;       /* sizeof(QsActorCritic) */
+    int32_t squash;
+    const float *wt1, *b1;      /* shared_fc0 [128,12], [128] */
+    const float *wt2, *b2;      /* pi_fc0     [128,128], [128] */
+    const float *wt3, *b3;      /* pi         [4,128], [4] */
+    const float *wtv2, *bv2;    /* vf_fc0     [128,128], [128] */
+    const float *wtv3, *bv3;    /* vf         [1,128], [1] */
+    float logstd[4];            /* pi/logstd (host values) */
+} QsActorCritic;
+int qs_runner_rollout(QsEnv *env, int64_t T, const QsActorCritic *policy, const float *noise /* nullable [T,N,4] */,
+                      const uint8_t *dones_in /* nullable [N] */, float *mb_obs /* [T,N,12] */,
+                      float *mb_actions /* [T,N,4] */, float *mb_values /* [T,N] */, float *mb_neglogp /* [T,N] */,
+                      uint8_t *mb_dones /* [T,N] */, float *mb_rewards /* [T,N] */, uint8_t *mb_flags /* nullable [T,N] */,
+                      float *last_obs /* nullable [N,12] */, float *last_values /* [N] */, uint8_t *last_dones /* [N] */);
+
 /* PID expert of run_expert_policy.py:49-69 / run_expert_record.py:121-136 for all N docking envs: from the handle's
  * current chaser / target states, des_vel = kp (p_target + (-0.2,0,0) - p_chaser) + kd (-v_chaser), vel_controller on
  * the chaser, action = (inv(rotor2control) u - action_mean) / action_std (not clipped).  state_des [N,13] in/out is

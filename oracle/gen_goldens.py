@@ -286,10 +286,13 @@ def gen_g5():
         F.append((1 if info["flag_docking"] else 0) | (2 if info["done_overlimit"] else 0) | (4 if env.t >= 600 else 0))
         if d:
             break
-    # the policy's weights are data (a float32 MLP 12 -> 128 -> 128 -> 4): kept as a fixture so the closed loop
-    # can be re-run on the GPU box, where the reference tree does not exist
+    # the policy's weights are data (a float32 MLP 12 -> 128 -> 128 -> 4, plus the value branch vf_fc0 -> vf and the
+    # Gaussian's logstd that PPO2's Runner uses): kept as a fixture so the closed loop can be re-run on the GPU box,
+    # where the reference tree does not exist
     save("policy_best_model_v0", w0=W["model/shared_fc0/w:0"], b0=W["model/shared_fc0/b:0"],
-         w1=W["model/pi_fc0/w:0"], b1=W["model/pi_fc0/b:0"], w2=W["model/pi/w:0"], b2=W["model/pi/b:0"])
+         w1=W["model/pi_fc0/w:0"], b1=W["model/pi_fc0/b:0"], w2=W["model/pi/w:0"], b2=W["model/pi/b:0"],
+         wv1=W["model/vf_fc0/w:0"], bv1=W["model/vf_fc0/b:0"], wv2=W["model/vf/w:0"], bv2=W["model/vf/b:0"],
+         logstd=W["model/pi/logstd:0"].reshape(-1))
     print("g5: steps %d, return %.4f, docked steps %d, last flags %d" % (
         len(A), float(np.sum(R)), int(np.sum(np.array(F) & 1)), F[-1]))
     save("g5_policy_episode", actions=np.array(A, np.float32), rec_before=np.array(RB), rec_after=np.array(RA),

@@ -261,6 +261,12 @@ class Oracle:
                                    _p(rr), _p(pn), _p(sc), _p(st), _p(par), _p(u))
         return sc, st, par, u
 
+    def normal4(self, seed, gid, k):
+        """four standard normals of (env gid, step k): POLICY stream, Box-Muller (qso_normal4)"""
+        n = np.zeros(4, self.dtype)
+        self._f("qso_normal4")(C.c_uint64(seed), C.c_uint64(gid), C.c_uint64(k), _p(n))
+        return n
+
     def random_action(self, seed, gid, k):
         a = np.zeros(4, np.float32)
         self._f("qso_random_action")(C.c_uint64(seed), C.c_uint64(gid), C.c_uint64(k), _p(a))
@@ -279,3 +285,33 @@ def rec_pack(chaser, target, u_c, u_t, qdes, last_shaping, t, dtype=np.float64):
     rec[..., 38] = last_shaping
     rec[..., 39] = t
     return rec
+
+
+def actor_critic_step(W, obs, noise, squash=False):
+    """float64 restatement of ``model.step(obs)`` of the PPO2 MlpPolicy the reference trains (TEST INFRASTRUCTURE).
+    Network: rl_baselines/common/policies.py:35-92 (mlp_extractor, net_arch [128, dict(vf=[128], pi=[128])], ReLU),
+    :583-588 (vf / pi heads); ``linear`` is stable_baselines.common.tf_layers.linear (x @ w + b; package absent here).
+    Distribution: rl_baselines/common/distributions.py:406-410 (neglogp), :426-430 (sample = mean + std * noise),
+    :412-415 and policies.py:238-242 (the fork's tanh variant, ``squash``).
+    Parity unpinned by reference outputs for value / neglogp (TensorFlow is not installed, so the reference's graph
+    cannot be executed); the action mean is pinned by fixture g5 (the reference env driven by these weights).
+    W: the arrays of tests/golden/policy_best_model_v0.npz.  obs [N,12], noise [N,4].
+    -> (u [N,4] sampled action, value [N], neglogp [N], env_action [N,4], mean [N,4])"""
+    f = lambda k: np.asarray(W[k], np.float64)                                    # noqa: E731
+    obs = np.asarray(obs, np.float64)
+    h = np.maximum(obs @ f("w0") + f("b0"), 0.0)
+    hp = np.maximum(h @ f("w1") + f("b1"), 0.0)
+    hv = np.maximum(h @ f("wv1") + f("bv1"), 0.0)
+    mean = hp @ f("w2") + f("b2")
+    value = (hv @ f("wv2") + f("bv2"))[:, 0]
+    logstd = f("logstd").reshape(1, -1)
+    std = np.exp(logstd)
+    u = mean + std * np.asarray(noise, np.float64)
+    neglogp = 0.5 * np.sum(np.square((u - mean) / std), axis=-1) + 0.5 * np.log(2.0 * np.pi) * u.shape[-1] \
+        + np.sum(logstd, axis=-1)
+    if squash:
+        env_action = np.tanh(u)
+        neglogp = neglogp + np.sum(np.log(1.0 - np.tanh(u) ** 2 + 1e-6), axis=1)
+    else:
+        env_action = np.clip(u, -1.0, 1.0)                                        # rl_baselines/ppo2/ppo2.py:483
+    return u, value, neglogp, env_action, mean

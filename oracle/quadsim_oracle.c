@@ -43,6 +43,7 @@ typedef float real;
 #define R_ASIN asinf
 #define R_ATAN2 atan2f
 #define R_FABS fabsf
+#define R_LOG logf
 #else
 typedef double real;
 #define FN(name) name##_f64
@@ -53,6 +54,7 @@ typedef double real;
 #define R_ASIN asin
 #define R_ATAN2 atan2
 #define R_FABS fabs
+#define R_LOG log
 #endif
 
 #define QSO_PI 3.14159265358979323846
@@ -555,6 +557,7 @@ float FN(qso_u01)(uint32_t v)
 #define STREAM_AUTORESET 0ull
 #define STREAM_RESET 1ull
 #define STREAM_ACTIONS 2ull
+#define STREAM_POLICY 4ull
 
 /* (0,1) uniform from 16 random bits: (h + 1/2) / 65536, exact in binary32 */
 static float u16f(uint32_t h) { return fmaf((float)h, 1.52587890625e-05f, 7.62939453125e-06f); }
@@ -617,6 +620,22 @@ void FN(qso_random_action)(uint64_t seed, uint64_t gid, uint64_t k, float a[4])
     int i;
     FN(qso_philox4x32_10)(seed, (STREAM_ACTIONS << 48) | gid, k, w);
     for (i = 0; i < 4; ++i) a[i] = fmaf(2.0f, FN(qso_u01)(w[i]), -1.0f);
+}
+
+/* four standard normals for (env gid, step k): Philox block k of the POLICY
+ * stream, Box-Muller on the (0,1] uniforms: (w0,w1) -> r cos, r sin; (w2,w3)
+ * likewise.  What the build draws in place of tf.random_normal in
+ * DiagGaussianProbabilityDistribution.sample (rl_baselines/common/distributions.py:426-430). */
+void FN(qso_normal4)(uint64_t seed, uint64_t gid, uint64_t k, real n[4])
+{
+    uint32_t w[4];
+    real r0, r1, a0, a1;
+    FN(qso_philox4x32_10)(seed, (STREAM_POLICY << 48) | gid, k, w);
+    r0 = R_SQRT((real)-2 * R_LOG((real)FN(qso_u01)(w[0])));
+    r1 = R_SQRT((real)-2 * R_LOG((real)FN(qso_u01)(w[2])));
+    a0 = (real)(2.0 * QSO_PI) * (real)FN(qso_u01)(w[1]);
+    a1 = (real)(2.0 * QSO_PI) * (real)FN(qso_u01)(w[3]);
+    n[0] = r0 * R_COS(a0); n[1] = r0 * R_SIN(a0); n[2] = r1 * R_COS(a1); n[3] = r1 * R_SIN(a1);
 }
 
 /* -------------------------------------------------------------------------

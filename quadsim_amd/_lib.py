@@ -26,6 +26,7 @@ EXPORTS = [
     "qs_rollout", "qs_rollout_slab", "qs_rollout_stepwise", "qs_fill_random_actions", "qs_get_state", "qs_set_state", "qs_set_params", "qs_get_params",
     "qs_set_init_state", "qs_get_init_state", "qs_obs_dim", "qs_get_step_counter", "qs_set_step_counter", "qs_set_stream", "qs_sync", "qs_timer_start", "qs_timer_stop",
     "qs_drone_step", "qs_ctrl", "qs_rel_obs", "qs_transform", "qs_gae", "qs_swap_and_flatten", "qs_expert_action", "qs_policy_rollout", "qs_policy_rollout_fast", "qs_policy_rollout_fast_blob_bytes",
+    "qs_runner_rollout",
 ]
 
 
@@ -37,6 +38,15 @@ class QsConfig(C.Structure):
         ("init_range", C.c_float * 4), ("mass_scale", C.c_float * 2), ("inertia_scale", C.c_float * 2),
         ("mass", C.c_float), ("inertia", C.c_float * 3), ("stream", C.c_void_p),
         ("external_stream", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+class QsActorCritic(C.Structure):
+    _fields_ = [
+        ("struct_size", C.c_uint32), ("squash", C.c_int32),
+        ("wt1", C.c_void_p), ("b1", C.c_void_p), ("wt2", C.c_void_p), ("b2", C.c_void_p),
+        ("wt3", C.c_void_p), ("b3", C.c_void_p), ("wtv2", C.c_void_p), ("bv2", C.c_void_p),
+        ("wtv3", C.c_void_p), ("bv3", C.c_void_p), ("logstd", C.c_float * 4),
     ]
 
 
@@ -119,6 +129,7 @@ def load():
         "qs_policy_rollout": [vp, i64] + [vp] * 11,
         "qs_policy_rollout_fast": [vp, i64] + [vp] * 6,
         "qs_policy_rollout_fast_blob_bytes": [],
+        "qs_runner_rollout": [vp, i64, C.POINTER(QsActorCritic)] + [vp] * 12,
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

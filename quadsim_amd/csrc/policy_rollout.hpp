@@ -119,6 +119,110 @@ __device__ __forceinline__ void mlp_actor(const float obs[12], float act[4], con
     __builtin_amdgcn_wave_barrier();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Actor-critic heads of the PPO2 MlpPolicy the reference trains (rl_baselines/common/policies.py:35-92 mlp_extractor
+// with net_arch [128, dict(vf=[128], pi=[128])], :583-588): shared_fc0 -> {pi_fc0 -> pi (mean), vf_fc0 -> vf (value)},
+// i.e. what model.step evaluates per Runner step (rl_baselines/ppo2/ppo2.py:475).  Same exact-f32 MFMA chaining as
+// mlp_actor; the value branch re-uses H1 and lands in row 4 of the 16-row output tile (rows 0..3 = action mean).
+// LDS image (floats): W2pi^T 128x132 | W2vf^T 128x132 | W3pi^T 4x132 | W3vf 132 | W1^T 128x13 | b1 128 | b2pi 128 |
+// b2vf 128 | b3 16 (mean biases, value bias at [4]) | per-wave stage 4 x 768  = 158 352 B of the CU's 160 KiB.
+struct AcArgs {
+    const float *wt1, *b1;      // shared_fc0: [128][12] (out, in), [128]
+    const float *wt2, *b2;      // pi_fc0:     [128][128], [128]
+    const float *wt3, *b3;      // pi:         [4][128], [4]
+    const float *wtv2, *bv2;    // vf_fc0:     [128][128], [128]
+    const float *wtv3, *bv3;    // vf:         [1][128], [1]
+};
+
+struct AcLds {
+    const float *W1, *B1, *W2p, *B2p, *W2v, *B2v, *W3p, *W3v, *B3;
+};
+
+constexpr size_t ac_lds_floats()
+{
+    return (size_t)2 * kHid * kLdW + 4 * kLdW + kLdW + kHid * kLdW1 + 3 * kHid + 16 + 4 * (12 * 64);
+}
+
+// obs (per owning lane) -> out[0..3] = action mean, out[4] = value (per owning lane).  `stage` = 768 floats per wave.
+__device__ __forceinline__ void mlp_actor_critic(const float obs[12], float out[5], const AcLds &L, float *stage, int lane)
+{
+    const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) stage[k * 64 + lane] = obs[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    f32x4 h1[8][4];
+    float xb[3][4];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int et = 0; et < 4; ++et) xb[s][et] = stage[(4 * s + g) * 64 + 16 * et + c];
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt) {
+        const f32x4 bias = *reinterpret_cast<const f32x4 *>(L.B1 + 16 * rt + 4 * g);
+        float a[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) a[s] = L.W1[(16 * rt + c) * kLdW1 + 4 * s + g];
+#pragma unroll
+        for (int et = 0; et < 4; ++et) {
+            f32x4 acc = bias;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], xb[s][et], acc, 0, 0, 0);
+            h1[rt][et] = relu4(acc);
+        }
+    }
+    f32x4 a3[4];
+    {
+        const f32x4 bias3 = *reinterpret_cast<const f32x4 *>(L.B3 + 4 * g);
+#pragma unroll
+        for (int et = 0; et < 4; ++et) a3[et] = bias3;
+    }
+    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+    for (int br = 0; br < 2; ++br) {                       // 0: policy branch -> rows 0..3, 1: value branch -> row 4
+        const float *W2 = br ? L.W2v : L.W2p;
+        const float *B2 = br ? L.B2v : L.B2p;
+#pragma unroll
+        for (int nt = 0; nt < 8; ++nt) {
+            const f32x4 bias = *reinterpret_cast<const f32x4 *>(B2 + 16 * nt + 4 * g);
+            f32x4 h2[4] = {bias, bias, bias, bias};
+#pragma unroll
+            for (int rt = 0; rt < 8; ++rt) {
+                const f32x4 w = *reinterpret_cast<const f32x4 *>(W2 + (16 * nt + c) * kLdW + 16 * rt + 4 * g);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int et = 0; et < 4; ++et)
+                        h2[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i], h1[rt][et][i], h2[et], 0, 0, 0);
+            }
+            // output-layer A operand: row c of the 16-row tile; only rows 0..3 (policy) / row 4 (value) are non-zero
+            f32x4 w3 = zero;
+            if (br == 0) { if (c < 4) w3 = *reinterpret_cast<const f32x4 *>(L.W3p + c * kLdW + 16 * nt + 4 * g); }
+            else { if (c == 4) w3 = *reinterpret_cast<const f32x4 *>(L.W3v + 16 * nt + 4 * g); }
+#pragma unroll
+            for (int et = 0; et < 4; ++et) {
+                const f32x4 r = relu4(h2[et]);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a3[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[i], r[i], a3[et], 0, 0, 0);
+            }
+        }
+    }
+    // rows 0..3 sit in lanes g == 0, row 4 in register 0 of lanes g == 1: hand them to the lane that owns the env
+    // (the stage is free again: every lane of this wave read its layer-1 operands long ago)
+    if (g == 0) {
+#pragma unroll
+        for (int et = 0; et < 4; ++et) *reinterpret_cast<f32x4 *>(stage + (16 * et + c) * 8) = a3[et];
+    } else if (g == 1) {
+#pragma unroll
+        for (int et = 0; et < 4; ++et) stage[(16 * et + c) * 8 + 4] = a3[et][0];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const f32x4 av = *reinterpret_cast<const f32x4 *>(stage + lane * 8);
+    out[0] = av[0]; out[1] = av[1]; out[2] = av[2]; out[3] = av[3];
+    out[4] = stage[lane * 8 + 4];
+    __builtin_amdgcn_wave_barrier();
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // Fast actor: the same MLP on the bf16 matrix rate (16x the f32 MFMA rate) with SPLIT operands.  Every f32 value v

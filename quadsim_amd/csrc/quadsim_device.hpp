@@ -35,7 +35,7 @@ constexpr int kParWords = 4;
 constexpr int F_SC = 0, F_ST = 13, F_UC = 26, F_UT = 30, F_QD = 34, F_LS = 38, F_T = 39;
 
 enum : unsigned { FLAG_DOCKED = 1, FLAG_OVERLIMIT = 2, FLAG_OVERTIME = 4, FLAG_CLIM = 8, FLAG_TLIM = 16 };
-enum : uint64_t { STREAM_AUTORESET = 0, STREAM_RESET = 1, STREAM_ACTIONS = 2 };
+enum : uint64_t { STREAM_AUTORESET = 0, STREAM_RESET = 1, STREAM_ACTIONS = 2, STREAM_CTOR = 3, STREAM_POLICY = 4 };
 
 struct Par {
     float m, Ixx, Iyy, Izz;
@@ -508,6 +508,31 @@ __device__ __forceinline__ void random_action(uint64_t seed, uint64_t gid, uint6
 {
     uint4 w = philox_block(seed, STREAM_ACTIONS, gid, k);
     a[0] = sym(u01(w.x)); a[1] = sym(u01(w.y)); a[2] = sym(u01(w.z)); a[3] = sym(u01(w.w));
+}
+
+// natural log / tanh on the hardware log2 / exp2 (1 ulp): policy sampling only, never on the env path
+__device__ __forceinline__ float q_ln(float x) { return __builtin_amdgcn_logf(x) * 0.693147180559945309f; }
+// tanh(x) and 1 - tanh(x)^2 = 4 e / (e + 1)^2, e = exp(2|x|): the second without the cancellation of 1 - t*t
+__device__ __forceinline__ float q_tanh(float x, float &sech2)
+{
+    float e = __builtin_amdgcn_exp2f(fminf(2.0f * fabsf(x), 60.0f) * 1.44269504088896341f);
+    float r = q_rcp(e + 1.0f);
+    sech2 = 4.0f * (e * r) * r;
+    return copysignf(1.0f - 2.0f * r, x);
+}
+
+// four standard normals for (env gid, step k): Philox block k of the POLICY stream, Box-Muller on (0,1] uniforms,
+// (w.x, w.y) -> n0 = r cos, n1 = r sin; (w.z, w.w) -> n2, n3.  Stands in for tf.random_normal in
+// DiagGaussianProbabilityDistribution.sample (rl_baselines/common/distributions.py:426-430); pinned in the oracle.
+__device__ __forceinline__ void random_normal4(uint64_t seed, uint64_t gid, uint64_t k, float n[4])
+{
+    uint4 w = philox_block(seed, STREAM_POLICY, gid, k);
+    float r0 = q_sqrt(-2.0f * q_ln(u01(w.x)));
+    float r1 = q_sqrt(-2.0f * q_ln(u01(w.z)));
+    float s0, c0, s1, c1;
+    q_sincos(2.0f * kPi * u01(w.y), s0, c0);
+    q_sincos(2.0f * kPi * u01(w.w), s1, c1);
+    n[0] = r0 * c0; n[1] = r0 * s0; n[2] = r1 * c1; n[3] = r1 * s1;
 }
 
 // per-env registers

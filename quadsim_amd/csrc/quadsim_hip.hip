@@ -311,6 +311,127 @@ __global__ __launch_bounds__(kBlock, 1) void k_policy_rollout_fast(StepArgs A, c
     if (active) { store_env(A.st, tile, lane, e); step_counter_end(A, tile, lane, k0); }
 }
 
+// PPO2 data collection in one launch: the Runner loop of rl_baselines/ppo2/ppo2.py:472-499 (+ last_values, :506) for
+// N envs and T = n_steps.  Per step: mb_obs <- obs; (mean, value) <- MLP heads on exact-f32 MFMA; action = mean +
+// std * N(0,1) (rocRAND Philox + Box-Muller, or caller-supplied noise); neglogp of the diagonal Gaussian
+// (common/distributions.py:406-410); env.step(clip(action, -1, 1)); mb_dones holds the done flags BEFORE the step
+// (ppo2.py:479), rewards / the new done after it.  squash: the fork's tanh variant (common/policies.py:238-242,
+// distributions.py:412-415): env gets tanh(u), neglogp += sum log(1 - tanh(u)^2 + 1e-6), mb_actions keeps u.
+struct RunnerArgs {
+    AcArgs net;
+    float std[4], inv_std[4];
+    float nl_const;            // 0.5 log(2 pi) * 4 + sum(logstd)
+    int squash;
+    const float *noise;        // nullable [T,N,4]
+    const uint8_t *dones_in;   // nullable [N]: done flags carried over from the previous run
+    float *actions;            // [T,N,4]
+    float *values;             // [T,N]
+    float *neglogp;            // [T,N]
+    float *last_obs;           // nullable [N,12]
+    float *last_values;        // [N]
+    uint8_t *last_dones;       // [N]
+};
+
+template <int INTEG, int RMODE>
+__global__ __launch_bounds__(kBlock, 1) void k_runner_rollout(StepArgs A, RunnerArgs R)
+{
+    __shared__ __attribute__((aligned(16))) float lds[ac_lds_floats()];
+    float *sW2p = lds;
+    float *sW2v = sW2p + kHid * kLdW;
+    float *sW3p = sW2v + kHid * kLdW;
+    float *sW3v = sW3p + 4 * kLdW;
+    float *sW1 = sW3v + kLdW;
+    float *sB1 = sW1 + kHid * kLdW1;
+    float *sB2p = sB1 + kHid;
+    float *sB2v = sB2p + kHid;
+    float *sB3 = sB2v + kHid;
+    float *sStage = sB3 + 16;
+    for (int i = threadIdx.x; i < kHid * kHid; i += kBlock) {
+        sW2p[(i >> 7) * kLdW + (i & 127)] = R.net.wt2[i];
+        sW2v[(i >> 7) * kLdW + (i & 127)] = R.net.wtv2[i];
+    }
+    for (int i = threadIdx.x; i < 4 * kHid; i += kBlock) sW3p[(i >> 7) * kLdW + (i & 127)] = R.net.wt3[i];
+    for (int i = threadIdx.x; i < kHid; i += kBlock) sW3v[i] = R.net.wtv3[i];
+    for (int i = threadIdx.x; i < kHid * 12; i += kBlock) sW1[(i / 12) * kLdW1 + (i % 12)] = R.net.wt1[i];
+    for (int i = threadIdx.x; i < kHid; i += kBlock) { sB1[i] = R.net.b1[i]; sB2p[i] = R.net.b2[i]; sB2v[i] = R.net.bv2[i]; }
+    if (threadIdx.x < 16) sB3[threadIdx.x] = threadIdx.x < 4 ? R.net.b3[threadIdx.x] : (threadIdx.x == 4 ? R.net.bv3[0] : 0.0f);
+    __syncthreads();
+    const AcLds L{sW1, sB1, sW2p, sB2p, sW2v, sB2v, sW3p, sW3v, sB3};
+
+    const int lane = threadIdx.x & (kTile - 1);
+    const int w = threadIdx.x >> 6;
+    const int64_t tile = (int64_t)blockIdx.x * (kBlock / kTile) + w;
+    const int64_t env = tile * kTile + lane;
+    const bool active = env < A.n;             // MFMA needs the whole wave: idle lanes carry a nominal env, store nothing
+    float *stage = sStage + w * (12 * 64);
+    Env e;
+    if (active) load_env(A.st, tile, lane, e);
+    else { nominal_init(e.sc, e.st); for (int i = 0; i < 4; ++i) { e.uc[i] = 0.0f; e.ut[i] = 0.0f; e.qd[i] = i == 0; } e.ls = 0.0f; e.t = 0.0f; }
+    Par P = A.par_nom;
+    const uint64_t k0 = active ? step_counter_begin(A, tile) : 0;
+    bool done_prev = (active && R.dones_in) ? R.dones_in[env] != 0 : false;
+    float obs[12];
+    rel_obs(e.sc, e.st, obs);
+#pragma clang loop unroll(disable)
+    for (int64_t t = 0; t < A.T; ++t) {
+        const int64_t o = t * A.n + env;
+        if (active) store_obs(A.obs, o, obs);                         // mb_obs: the observation the policy acts on
+        float head[5];
+        mlp_actor_critic(obs, head, L, stage, lane);
+        float eps[4];
+        if (R.noise) {
+            const float4 nv = active ? reinterpret_cast<const float4 *>(R.noise)[o] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+            eps[0] = nv.x; eps[1] = nv.y; eps[2] = nv.z; eps[3] = nv.w;
+        } else {
+            random_normal4(A.rc.seed, A.gid0 + (uint64_t)(active ? env : 0), k0 + (uint64_t)t, eps);
+        }
+        float u[4], a[4];
+        float nl = R.nl_const;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            u[i] = fmaf(R.std[i], eps[i], head[i]);                   // distributions.py:429
+            const float d = (u[i] - head[i]) * R.inv_std[i];          // :407
+            nl = fmaf(0.5f * d, d, nl);
+        }
+        if (R.squash) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                float sech2;
+                a[i] = q_tanh(u[i], sech2);                           // policies.py:238
+                nl += q_ln(sech2 + 1e-6f);                            // distributions.py:414, 1 - tanh(u)^2 + 1e-6
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = fminf(fmaxf(u[i], -1.0f), 1.0f);   // ppo2.py:483
+        }
+        if (active) {
+            reinterpret_cast<float4 *>(R.actions)[o] = make_float4(u[0], u[1], u[2], u[3]);
+            R.values[o] = head[4];
+            R.neglogp[o] = nl;
+            A.done[o] = done_prev ? 1 : 0;                            // mb_dones: flags before the step (ppo2.py:479)
+        }
+        float reward;
+        unsigned flags;
+        bool done;
+        step_and_maybe_reset<INTEG, false, RMODE>(e, P, a, A, active ? env : 0, k0 + (uint64_t)t, obs, reward, flags, done, false);
+        done_prev = done;
+        if (active) {
+            A.reward[o] = reward;
+            if (A.flags) A.flags[o] = (uint8_t)flags;
+        }
+    }
+    // last_values = model.value(obs) on the observation after the last step (ppo2.py:506)
+    float head[5];
+    mlp_actor_critic(obs, head, L, stage, lane);
+    if (active) {
+        R.last_values[env] = head[4];
+        R.last_dones[env] = done_prev ? 1 : 0;
+        if (R.last_obs) store_obs(R.last_obs, env, obs);
+        store_env(A.st, tile, lane, e);
+        step_counter_end(A, tile, lane, k0);
+    }
+}
+
 // hovering-v0 (HoveringEnv.step, hovering_env.py:47-78): T fused steps, one drone per lane.  Uses rows F_SC..
 // (state) and F_UC.. (last limited control) of the tile; obs [T,N,13] = state after the step (or the stored
 // ini_state after an auto-reset, hovering_env.py:80-82).
@@ -374,7 +495,7 @@ __global__ __launch_bounds__(kBlock) void k_ctor_init(float *init, int64_t n, in
 {
     const int64_t env = (int64_t)blockIdx.x * kBlock + threadIdx.x;
     if (env >= n) return;
-    uint4 w = philox_block(seed, 3ull, gid0 + (uint64_t)env, 0);
+    uint4 w = philox_block(seed, STREAM_CTOR, gid0 + (uint64_t)env, 0);
     if (!hover) {
         float *d = init + env * 26;
         for (int i = 0; i < 26; ++i) d[i] = 0.0f;
@@ -1367,6 +1488,48 @@ int qs_policy_rollout_fast(QsEnv *e, int64_t T, const void *packed_weights, floa
 }
 
 int qs_policy_rollout_fast_blob_bytes(void) { return kFastBlobBytes; }
+
+int qs_runner_rollout(QsEnv *e, int64_t T, const QsActorCritic *pol, const float *noise, const uint8_t *dones_in,
+                      float *mb_obs, float *mb_actions, float *mb_values, float *mb_neglogp, uint8_t *mb_dones,
+                      float *mb_rewards, uint8_t *mb_flags, float *last_obs, float *last_values, uint8_t *last_dones)
+{
+    CHECK_ENV(e);
+    if (T < 1 || !pol || !mb_obs || !mb_actions || !mb_values || !mb_neglogp || !mb_dones || !mb_rewards || !last_values
+        || !last_dones)
+        return fail(QS_ERR_INVALID, "qs_runner_rollout: bad arguments");
+    if (pol->struct_size != sizeof(QsActorCritic)) return fail(QS_ERR_INVALID, "qs_runner_rollout: QsActorCritic.struct_size mismatch");
+    if (!pol->wt1 || !pol->b1 || !pol->wt2 || !pol->b2 || !pol->wt3 || !pol->b3 || !pol->wtv2 || !pol->bv2 || !pol->wtv3 || !pol->bv3)
+        return fail(QS_ERR_INVALID, "qs_runner_rollout: null weight pointer");
+    if (e->cfg.io_space != QS_IO_DEVICE) return fail(QS_ERR_INVALID, "qs_runner_rollout: device buffers only");
+    if (!e->cfg.auto_reset) return fail(QS_ERR_INVALID, "qs_runner_rollout: requires auto_reset");
+    if (e->cfg.kind == QS_KIND_HOVERING_V0 || e->per_env_params || e->init || e->cfg.randomise > 1)
+        return fail(QS_ERR_INVALID, "qs_runner_rollout: docking-v0/v2 with nominal or rocRAND-initialised resets only");
+    StepArgs A = make_args(e);
+    A.T = T; A.obs = mb_obs; A.reward = mb_rewards; A.done = mb_dones; A.flags = mb_flags;
+    RunnerArgs R{};
+    R.net = AcArgs{pol->wt1, pol->b1, pol->wt2, pol->b2, pol->wt3, pol->b3, pol->wtv2, pol->bv2, pol->wtv3, pol->bv3};
+    double ls = 0.0;
+    for (int i = 0; i < 4; ++i) {
+        if (!(pol->logstd[i] == pol->logstd[i])) return fail(QS_ERR_INVALID, "qs_runner_rollout: logstd is NaN");
+        R.std[i] = expf(pol->logstd[i]);
+        R.inv_std[i] = 1.0f / R.std[i];
+        ls += (double)pol->logstd[i];
+    }
+    R.nl_const = (float)(0.5 * 1.8378770664093453 * 4.0 + ls);      // 0.5 log(2 pi) d + sum logstd
+    R.squash = pol->squash;
+    R.noise = noise; R.dones_in = dones_in;
+    R.actions = mb_actions; R.values = mb_values; R.neglogp = mb_neglogp;
+    R.last_obs = last_obs; R.last_values = last_values; R.last_dones = last_dones;
+    const unsigned grid = grid_tiles(e->n);
+    const bool fr = e->cfg.integrator == QS_INTEG_FROZEN;
+    const int rm = e->cfg.randomise;
+    if (fr && rm == 0) hipLaunchKernelGGL((k_runner_rollout<0, 0>), dim3(grid), dim3(kBlock), 0, e->stream, A, R);
+    else if (fr) hipLaunchKernelGGL((k_runner_rollout<0, 1>), dim3(grid), dim3(kBlock), 0, e->stream, A, R);
+    else if (rm == 0) hipLaunchKernelGGL((k_runner_rollout<1, 0>), dim3(grid), dim3(kBlock), 0, e->stream, A, R);
+    else hipLaunchKernelGGL((k_runner_rollout<1, 1>), dim3(grid), dim3(kBlock), 0, e->stream, A, R);
+    HIP_TRY(hipGetLastError());
+    return QS_OK;
+}
 
 int qs_expert_action(QsEnv *e, float *state_des, float kp, float kd, float *actions)
 {

@@ -1,0 +1,179 @@
+"""PPO2 data collection on the device: the in-tree trainer's ``Runner`` (rl_baselines/ppo2/ppo2.py:438-527) over a
+``VecDockingEnv``, with the whole ``for _ in range(n_steps)`` loop -- policy and value networks, Gaussian sampling,
+neglogp, action clipping, ``env.step``, roll-out storage -- in ONE kernel launch (``qs_runner_rollout``), followed by
+the GAE kernel and ``swap_and_flatten``.  Same class / method names and return tuple as the reference.
+
+``ActorCriticPolicy`` is the MlpPolicy the reference trains and ships (``trained_model/best_model_v0.zip``:
+shared_fc0 12->128, pi_fc0 / vf_fc0 128->128, pi 128->4, vf 128->1, ReLU, state-independent logstd;
+rl_baselines/common/policies.py:35-92,:583-603).  Its ``step`` / ``value`` are plain torch (library GEMMs) and serve
+the per-step API; the fused kernel evaluates the same network on the matrix cores in exact float32.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from .rollout_buffer import compute_gae, swap_and_flatten
+
+
+class ActorCriticPolicy:
+    def __init__(self, weights, device="cuda", squash=False):
+        import torch
+        self.torch = torch
+        g = lambda k: torch.as_tensor(np.ascontiguousarray(weights[k], np.float32)).to(device)  # noqa: E731
+        self.w0, self.b0 = g("w0"), g("b0")            # shared_fc0
+        self.w1, self.b1 = g("w1"), g("b1")            # pi_fc0
+        self.w2, self.b2 = g("w2"), g("b2")            # pi
+        self.wv1, self.bv1 = g("wv1"), g("bv1")        # vf_fc0
+        self.wv2, self.bv2 = g("wv2"), g("bv2")        # vf
+        self.logstd_host = np.asarray(weights["logstd"], np.float32).reshape(4).copy()
+        self.logstd = torch.as_tensor(self.logstd_host).to(device)
+        self.squash = bool(squash)
+        self.initial_state = None
+        self._wt = None
+
+    @classmethod
+    def from_npz(cls, path, device="cuda", squash=False):
+        with np.load(path, allow_pickle=False) as z:
+            return cls({k: z[k] for k in z.files}, device, squash)
+
+    # -- model.step / model.value (policies.py:592-609) on torch ----------------------------------------------------
+    def _heads(self, obs):
+        t = self.torch
+        h = t.relu(t.addmm(self.b0, obs, self.w0))
+        mean = t.addmm(self.b2, t.relu(t.addmm(self.b1, h, self.w1)), self.w2)
+        value = t.addmm(self.bv2, t.relu(t.addmm(self.bv1, h, self.wv1)), self.wv2)[:, 0]
+        return mean, value
+
+    def step(self, obs, state=None, mask=None, deterministic=False, noise=None):
+        """-> (actions [N,4] (un-clipped sample), values [N], states None, neglogp [N]); `noise` [N,4] replaces the
+        generator's normals (tests)"""
+        t = self.torch
+        mean, value = self._heads(obs)
+        std = t.exp(self.logstd)
+        if deterministic:
+            u = mean
+        else:
+            eps = t.randn_like(mean) if noise is None else noise
+            u = mean + std * eps
+        nl = 0.5 * (((u - mean) / std) ** 2).sum(-1) + 0.5 * math.log(2.0 * math.pi) * u.shape[-1] + self.logstd.sum()
+        if self.squash:
+            nl = nl + t.log(1.0 - t.tanh(u) ** 2 + 1e-6).sum(-1)
+        return u, value, self.initial_state, nl
+
+    def env_action(self, u):
+        """what the env receives: clip to the action box (ppo2.py:483), or tanh(u) in the fork's squashed variant"""
+        return self.torch.tanh(u) if self.squash else self.torch.clamp(u, -1.0, 1.0)
+
+    def value(self, obs, state=None, mask=None):
+        return self._heads(obs)[1]
+
+    # -- device image for the fused kernel --------------------------------------------------------------------------
+    def c_struct(self):
+        if self._wt is None:
+            tr = lambda w: w.t().contiguous()                                                  # noqa: E731
+            self._wt = [tr(self.w0), self.b0.contiguous(), tr(self.w1), self.b1.contiguous(), tr(self.w2),
+                        self.b2.contiguous(), tr(self.wv1), self.bv1.contiguous(), tr(self.wv2), self.bv2.contiguous()]
+        s = _lib.QsActorCritic()
+        s.struct_size = C.sizeof(_lib.QsActorCritic)
+        s.squash = 1 if self.squash else 0
+        for name, w in zip(("wt1", "b1", "wt2", "b2", "wt3", "b3", "wtv2", "bv2", "wtv3", "bv3"), self._wt):
+            setattr(s, name, w.data_ptr())
+        for i in range(4):
+            s.logstd[i] = float(self.logstd_host[i])
+        return s
+
+
+def fused_runner_rollout(env, policy, T, noise=None, dones_in=None, want_flags=False):
+    """qs_runner_rollout: T Runner steps for all envs in one launch, from the envs' current state.
+    -> dict of device tensors: obs [T,N,12] (the observations acted on), actions [T,N,4] (un-clipped samples),
+    values, neglogp, rewards [T,N] f32, dones [T,N] u8 (flags BEFORE each step), flags [T,N] u8 or None,
+    last_obs [N,12], last_values [N], last_dones [N] u8."""
+    import torch
+    n, dev = env.num_envs, env.device
+    f32, u8 = torch.float32, torch.uint8
+    out = {
+        "obs": torch.empty((T, n, 12), dtype=f32, device=dev), "actions": torch.empty((T, n, 4), dtype=f32, device=dev),
+        "values": torch.empty((T, n), dtype=f32, device=dev), "neglogp": torch.empty((T, n), dtype=f32, device=dev),
+        "dones": torch.empty((T, n), dtype=u8, device=dev), "rewards": torch.empty((T, n), dtype=f32, device=dev),
+        "flags": torch.empty((T, n), dtype=u8, device=dev) if want_flags else None,
+        "last_obs": torch.empty((n, 12), dtype=f32, device=dev), "last_values": torch.empty((n,), dtype=f32, device=dev),
+        "last_dones": torch.empty((n,), dtype=u8, device=dev),
+    }
+    if noise is not None:
+        noise = noise.to(device=dev, dtype=f32).contiguous()
+        if tuple(noise.shape) != (T, n, 4):
+            raise ValueError("noise must be [T, num_envs, 4]")
+    if dones_in is not None:
+        dones_in = dones_in.to(device=dev).to(u8).contiguous()
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None      # noqa: E731
+    env._use_current_stream()
+    pol = policy.c_struct()
+    _lib.check(env._lib.qs_runner_rollout(env._h, T, C.byref(pol), p(noise), p(dones_in), p(out["obs"]), p(out["actions"]),
+                                          p(out["values"]), p(out["neglogp"]), p(out["dones"]), p(out["rewards"]),
+                                          p(out["flags"]), p(out["last_obs"]), p(out["last_values"]), p(out["last_dones"])),
+               "qs_runner_rollout")
+    return out
+
+
+class Runner:
+    """rl_baselines/ppo2/ppo2.py:438-527.  ``run()`` returns the reference's 9-tuple
+    (obs, returns, masks, actions, values, neglogpacs, states, ep_infos, true_reward), every array flattened env-major by
+    ``swap_and_flatten`` and resident on the device.  ``reset_after_run`` reproduces the fork's ``self.obs =
+    self.env.reset()`` after every roll-out (:525); stable-baselines proper keeps the envs running (default).
+    ``ep_infos`` lists {'r': episode return, 'l': length} of the episodes that ended inside the roll-out (what the
+    Monitor wrapper of run_docking_ppo2.py:19-35 reports through ``info['episode']``)."""
+
+    def __init__(self, *, env, model, n_steps, gamma, lam, reset_after_run=False, collect_ep_infos=True):
+        import torch
+        self.torch = torch
+        self.env, self.model, self.n_steps, self.gamma, self.lam = env, model, int(n_steps), float(gamma), float(lam)
+        self.reset_after_run = reset_after_run
+        self.collect_ep_infos = collect_ep_infos
+        self.obs = env.reset()
+        self.states = model.initial_state
+        self.dones = torch.zeros((env.num_envs,), dtype=torch.uint8, device=env.device)
+        self._ep_ret = torch.zeros((env.num_envs,), dtype=torch.float32, device=env.device)
+        self._ep_len = torch.zeros((env.num_envs,), dtype=torch.int64, device=env.device)
+        self.num_timesteps = 0
+
+    def _episode_infos(self, rewards, done_after):
+        """returns / lengths of the episodes that ended inside this roll-out (segmented sums over [T,N], no host loop)"""
+        t = self.torch
+        T, n = rewards.shape
+        csum = rewards.cumsum(0)
+        idx = t.arange(T, device=rewards.device).view(T, 1).expand(T, n)
+        last = t.where(done_after, idx, t.full_like(idx, -1)).cummax(0).values       # latest done at or before t
+        prev = t.cat([t.full((1, n), -1, dtype=idx.dtype, device=idx.device), last[:-1]], 0)
+        base = t.where(prev >= 0, csum.gather(0, prev.clamp(min=0)), -self._ep_ret.view(1, n).expand(T, n))
+        ret = csum - base
+        length = t.where(prev >= 0, idx - prev, idx + 1 + self._ep_len.view(1, n))
+        # carry the unfinished episodes into the next run
+        lastd = last[-1]
+        tail = csum[-1] - t.where(lastd >= 0, csum.gather(0, lastd.clamp(min=0).view(1, n))[0], -self._ep_ret)
+        self._ep_ret = tail
+        self._ep_len = t.where(lastd >= 0, (T - 1) - lastd, self._ep_len + T)
+        r = ret[done_after].cpu().numpy()
+        l_ = length[done_after].cpu().numpy()
+        return [{"r": float(a), "l": int(b)} for a, b in zip(r, l_)]
+
+    def run(self, noise=None):
+        t = self.torch
+        env, T = self.env, self.n_steps
+        mb_states = self.states
+        ro = fused_runner_rollout(env, self.model, T, noise=noise, dones_in=self.dones)
+        self.num_timesteps += T * env.num_envs
+        mb_advs, mb_returns = compute_gae(env, ro["rewards"], ro["values"], ro["dones"], ro["last_values"],
+                                          ro["last_dones"], self.gamma, self.lam)          # ppo2.py:507-520
+        ep_infos = []
+        if self.collect_ep_infos:
+            done_after = t.cat([ro["dones"][1:], ro["last_dones"].view(1, -1)], 0).bool()
+            ep_infos = self._episode_infos(ro["rewards"], done_after)
+        self.obs, self.dones = ro["last_obs"], ro["last_dones"]
+        flat = lambda x: swap_and_flatten(env, x)                                          # noqa: E731  ppo2.py:522-523
+        out = (flat(ro["obs"]), flat(mb_returns), flat(ro["dones"]).bool(), flat(ro["actions"]), flat(ro["values"]),
+               flat(ro["neglogp"]), mb_states, ep_infos, flat(ro["rewards"]))
+        if self.reset_after_run:
+            self.obs = env.reset()                                                         # ppo2.py:525
+        return out

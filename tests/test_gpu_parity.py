@@ -929,3 +929,148 @@ def test_env_step_adversarial_states_vs_oracle(qa, env_id, kind):
     assert np.all(np.abs(obs[far, 9:] - o[far, 9:]) <= 1e-4 * scale * (1 + np.abs(np.tan(o[far, 6]))[:, None]))
     assert np.array_equal(done[ok], d[ok].astype(bool))
     assert sat.sum() > 100 and far.sum() > 3000
+
+
+# ---------------------------------------------------------------- PPO2 Runner: data collection in one launch
+def _ac_policy(qa, squash=False):
+    import os
+    from conftest import GOLDEN
+    path = os.path.join(GOLDEN, "policy_best_model_v0.npz")
+    with np.load(path, allow_pickle=False) as z:
+        W = {k: z[k] for k in z.files}
+    return qa.ActorCriticPolicy.from_npz(path, squash=squash), W
+
+
+@pytest.mark.parametrize("squash", [False, True])
+def test_runner_rollout_one_step_vs_oracle(qa, squash):
+    """qs_runner_rollout, T = 1, against the float64 restatement of model.step (oracle.pyoracle.actor_critic_step) on the
+    observations the kernel reports, and against the oracle's env.step fed with the kernel's own env actions; ragged N
+    (idle lanes inside the MFMA wave).  value / neglogp are parity-unpinned by reference outputs (no TensorFlow here)."""
+    import torch
+    from oracle.pyoracle import actor_critic_step
+    pol, W = _ac_policy(qa, squash)
+    n, seed = 1000, 7
+    env = qa.VecDockingEnv("docking-v0", num_envs=n, randomise=1, seed=seed, init_range=qa.C3_INIT_RANGE)
+    obs0 = env.reset().cpu().numpy()
+    t_boost = np.zeros(n, np.float32); t_boost[::5] = 599.0           # every fifth env times out on this step
+    env.set_state(t=t_boost)
+    rec = state_to_rec(env.get_state()); par = tile_par(n)
+    g = torch.Generator().manual_seed(3)
+    noise = torch.randn((1, n, 4), generator=g) * 3.0                  # wide: exercises the clip / tanh saturation
+    k0 = env.step_counter
+    ro = qa.fused_runner_rollout(env, pol, 1, noise=noise, want_flags=True)
+    R = {k: (v.cpu().numpy() if v is not None else None) for k, v in ro.items()}
+    np.testing.assert_allclose(R["obs"][0], obs0, rtol=1e-6, atol=1e-6)   # mb_obs[0] = the observation acted on
+    assert not R["dones"].any()
+    u, value, nl, a_env, mean = actor_critic_step(W, R["obs"][0], noise[0].numpy(), squash)
+    np.testing.assert_allclose(R["actions"][0], u, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(R["values"][0], value, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(R["neglogp"][0], nl, rtol=2e-5, atol=2e-4)   # 0.5 * (u-mean)^2/std^2 with std ~ 0.07
+    # env side: the oracle steps from the pre-launch state with the env actions of the GPU's own samples
+    a_gpu = np.tanh(R["actions"][0].astype(np.float64)) if squash else np.clip(R["actions"][0], -1.0, 1.0)
+    orc = Oracle("f64")
+    o, r, d, f, term = orc.vec_step(rec, par, a_gpu.astype(np.float32), kind=0, randomise=1, seed=seed, step_idx=k0,
+                                    rr=tuple(qa.C3_INIT_RANGE) + (1, 1, 1, 1), want_term=True)
+    assert d[::5].all() and np.array_equal(R["last_dones"], d)
+    np.testing.assert_allclose(R["last_obs"], o, **OBS_TOL)
+    assert np.all(np.abs(R["rewards"][0] - r) <= reward_atol(rec[:, 38]) + reward_atol(r))
+    assert np.array_equal(R["flags"][0] & 7, f & 7)
+    rec2 = state_to_rec(env.get_state())
+    np.testing.assert_allclose(rec2[:, :38], rec[:, :38], **STATE_TOL)
+    u2, v2, _, _, _ = actor_critic_step(W, R["last_obs"], np.zeros((n, 4)), squash)
+    np.testing.assert_allclose(R["last_values"], v2, rtol=1e-5, atol=1e-5)   # model.value on the final observation
+    assert env.step_counter == k0 + 1
+    env.close()
+
+
+def test_runner_rollout_equals_stepwise_loop(qa):
+    """the fused Runner loop against the same loop spelt out step by step (torch GEMMs for model.step, qs_step for the
+    env) with identical noise: same samples, values, neglogp, rewards, dones-before-step bookkeeping"""
+    import torch
+    pol, _ = _ac_policy(qa)
+    T, n = 40, 777
+    kw = dict(num_envs=n, randomise=1, seed=5, init_range=qa.C3_INIT_RANGE)
+    e1 = qa.VecDockingEnv("docking-v0", **kw); e2 = qa.VecDockingEnv("docking-v0", **kw)
+    obs = e1.reset(); e2.reset()
+    e1.set_state(t=np.full(n, 575.0, np.float32)); e2.set_state(t=np.full(n, 575.0, np.float32))   # time-outs at step 25
+    noise = torch.randn((T, n, 4), generator=torch.Generator().manual_seed(1)).to(e1.device)
+    ro = qa.fused_runner_rollout(e2, pol, T, noise=noise)
+    O, A, V, NL, D, Rw = [], [], [], [], [], []
+    dones = torch.zeros(n, dtype=torch.bool, device=e1.device)
+    for t in range(T):
+        u, v, _, nl = pol.step(obs, noise=noise[t])
+        O.append(obs.clone()); A.append(u); V.append(v); NL.append(nl); D.append(dones.clone())
+        obs, r, dones, _ = e1.step(pol.env_action(u))
+        obs, dones = obs.clone(), dones.clone()
+        Rw.append(r.clone())
+    O, A, V, NL, D, Rw = (torch.stack(x).cpu().numpy() for x in (O, A, V, NL, D, Rw))
+    G = {k: v.cpu().numpy() for k, v in ro.items() if v is not None}
+    assert np.array_equal(G["dones"].astype(bool), D) and D[25].all() and D[:25].mean() < 0.01
+    assert np.array_equal(G["last_dones"].astype(bool), dones.cpu().numpy())
+    np.testing.assert_allclose(G["actions"][0], A[0], atol=2e-6)
+    np.testing.assert_allclose(G["obs"], O, rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(G["actions"], A, atol=2e-3)
+    np.testing.assert_allclose(G["values"], V, rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(G["neglogp"], NL, rtol=1e-3, atol=2e-2)
+    np.testing.assert_allclose(G["rewards"], Rw, atol=5e-3)
+    np.testing.assert_allclose(G["last_obs"], obs.cpu().numpy(), rtol=2e-3, atol=2e-3)
+    np.testing.assert_allclose(G["last_values"], pol.value(obs).cpu().numpy(), rtol=2e-3, atol=2e-3)
+    assert e1.step_counter == e2.step_counter == T
+    e1.close(); e2.close()
+
+
+def test_runner_rollout_in_kernel_normals(qa, oracle64):
+    """noise = None: the kernel draws its normals from rocRAND Philox (stream 4, block = global step) + Box-Muller;
+    the oracle restates the draw (qso_normal4) -- samples match, and the moments over 8 x 65 536 draws are standard"""
+    from oracle.pyoracle import actor_critic_step
+    pol, W = _ac_policy(qa)
+    n, T, seed, off = 16384, 2, 21, 5000
+    env = qa.VecDockingEnv("docking-v0", num_envs=n, randomise=1, seed=seed, init_range=qa.C3_INIT_RANGE, env_id_offset=off)
+    env.reset()
+    env.step(env.random_actions(1)[0])                                  # global step counter 1 at launch
+    k0 = env.step_counter
+    ro = qa.fused_runner_rollout(env, pol, T)
+    obs, act = ro["obs"].cpu().numpy(), ro["actions"].cpu().numpy()
+    std = np.exp(W["logstd"].astype(np.float64))
+    eps = np.zeros((T, n, 4))
+    for t in range(T):
+        mean = actor_critic_step(W, obs[t], np.zeros((n, 4)))[4]
+        eps[t] = (act[t] - mean) / std
+    for t, i in [(0, 0), (0, 1), (1, 63), (0, 64), (1, 4097), (1, n - 1)]:
+        np.testing.assert_allclose(eps[t, i], oracle64.normal4(seed, off + i, k0 + t), atol=3e-4)
+    assert abs(eps.mean()) < 0.01 and abs(eps.var() - 1.0) < 0.02 and abs((eps ** 4).mean() - 3.0) < 0.1
+    assert abs(np.corrcoef(eps[0, :, 0], eps[0, :, 1])[0, 1]) < 0.03
+    env.close()
+
+
+def test_runner_run_matches_reference_bookkeeping(qa, oracle64):
+    """Runner.run(): the reference's 9-tuple (rl_baselines/ppo2/ppo2.py:522-527) -- GAE on the roll-out's own rewards /
+    values / dones (oracle: qso_gae), env-major flattening, dones carried into the next run, episode infos"""
+    pol, _ = _ac_policy(qa)
+    n, T = 300, 50
+    env = qa.VecDockingEnv("docking-v0", num_envs=n, randomise=1, seed=9, init_range=qa.C3_INIT_RANGE)
+    runner = qa.Runner(env=env, model=pol, n_steps=T, gamma=0.99, lam=0.95)
+    env.set_state(t=np.linspace(540.0, 599.0, n).astype(np.float32))    # staggered time-outs inside both runs
+    ep_ret = np.zeros(n); ep_len = np.zeros(n, np.int64)
+    for it in range(2):
+        d_in = runner.dones.cpu().numpy().copy()
+        obs, returns, masks, actions, values, neglogp, states, ep_infos, true_reward = runner.run()
+        f = lambda x: x.cpu().numpy().reshape(n, T, *x.shape[1:]).swapaxes(0, 1)      # noqa: E731  undo swap_and_flatten
+        mb_rew, mb_val, mb_done, mb_ret = f(true_reward), f(values), f(masks), f(returns)
+        assert np.array_equal(mb_done[0], d_in.astype(bool))            # self.dones survives between runs (ppo2.py:479)
+        last_v = pol.value(runner.obs).cpu().numpy(); last_d = runner.dones.cpu().numpy()
+        adv, ret = oracle64.gae(mb_rew, mb_val, mb_done.astype(np.uint8), last_v, last_d, 0.99, 0.95)
+        np.testing.assert_allclose(mb_ret, ret, rtol=1e-4, atol=1e-4)
+        assert obs.shape == (n * T, 12) and actions.shape == (n * T, 4) and neglogp.shape == (n * T,) and states is None
+        # episode infos: plain loop over the [T,N] rewards / done-after-step flags
+        done_after = np.concatenate([mb_done[1:], last_d[None].astype(bool)], 0)
+        want = []
+        for t in range(T):
+            ep_ret += mb_rew[t]; ep_len += 1
+            for i in np.nonzero(done_after[t])[0]:
+                want.append((ep_ret[i], ep_len[i])); ep_ret[i] = 0.0; ep_len[i] = 0
+        assert len(ep_infos) == len(want) > 100
+        assert [e["l"] for e in ep_infos] == [int(l_) for _, l_ in want]            # same (step, env) order as the loop
+        np.testing.assert_allclose([e["r"] for e in ep_infos], [r for r, _ in want], atol=2e-3)
+    assert runner.num_timesteps == 2 * n * T
+    env.close()
