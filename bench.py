@@ -275,7 +275,7 @@ def main():
             # neglogp + env.step for n_steps in one launch, then the GAE kernel and the env-major flatten of 7 arrays
             from quadsim_amd import ActorCriticPolicy, Runner
             ac = ActorCriticPolicy.from_npz(wpath, device="cuda:%d" % local_rank)
-            runner = Runner(env=env, model=ac, n_steps=Tp, gamma=0.99, lam=0.95, collect_ep_infos=False)
+            runner = Runner(env=env, model=ac, n_steps=Tp, gamma=0.99, lam=0.95, track_episodes=False)
             runner.run()
             barrier()
             t0 = time.perf_counter()

@@ -59,7 +59,8 @@ class ActorCriticPolicy:
             u = mean + std * eps
         nl = 0.5 * (((u - mean) / std) ** 2).sum(-1) + 0.5 * math.log(2.0 * math.pi) * u.shape[-1] + self.logstd.sum()
         if self.squash:
-            nl = nl + t.log(1.0 - t.tanh(u) ** 2 + 1e-6).sum(-1)
+            # distributions.py:414 with 1 - tanh(u)^2 evaluated as sech(u)^2: no float32 cancellation once tanh saturates
+            nl = nl + t.log(t.cosh(u.clamp(-30.0, 30.0)) ** -2 + 1e-6).sum(-1)
         return u, value, self.initial_state, nl
 
     def env_action(self, u):
@@ -123,14 +124,18 @@ class Runner:
     ``swap_and_flatten`` and resident on the device.  ``reset_after_run`` reproduces the fork's ``self.obs =
     self.env.reset()`` after every roll-out (:525); stable-baselines proper keeps the envs running (default).
     ``ep_infos`` lists {'r': episode return, 'l': length} of the episodes that ended inside the roll-out (what the
-    Monitor wrapper of run_docking_ppo2.py:19-35 reports through ``info['episode']``)."""
+    Monitor wrapper of run_docking_ppo2.py:19-35 reports through ``info['episode']``); with tens of thousands of envs
+    prefer ``collect_ep_infos=False`` and read the device tensors ``last_ep_returns`` / ``last_ep_lengths``."""
 
-    def __init__(self, *, env, model, n_steps, gamma, lam, reset_after_run=False, collect_ep_infos=True):
+    def __init__(self, *, env, model, n_steps, gamma, lam, reset_after_run=False, collect_ep_infos=True,
+                 track_episodes=True):
         import torch
         self.torch = torch
         self.env, self.model, self.n_steps, self.gamma, self.lam = env, model, int(n_steps), float(gamma), float(lam)
         self.reset_after_run = reset_after_run
-        self.collect_ep_infos = collect_ep_infos
+        self.collect_ep_infos = collect_ep_infos       # build the reference's list of {'r', 'l'} dicts on the host
+        self.track_episodes = track_episodes           # keep episode returns / lengths at all (device tensors
+        self.last_ep_returns = self.last_ep_lengths = None   # last_ep_returns / last_ep_lengths after each run)
         self.obs = env.reset()
         self.states = model.initial_state
         self.dones = torch.zeros((env.num_envs,), dtype=torch.uint8, device=env.device)
@@ -154,8 +159,11 @@ class Runner:
         tail = csum[-1] - t.where(lastd >= 0, csum.gather(0, lastd.clamp(min=0).view(1, n))[0], -self._ep_ret)
         self._ep_ret = tail
         self._ep_len = t.where(lastd >= 0, (T - 1) - lastd, self._ep_len + T)
-        r = ret[done_after].cpu().numpy()
-        l_ = length[done_after].cpu().numpy()
+        self.last_ep_returns, self.last_ep_lengths = ret[done_after], length[done_after]     # device tensors, (t, env) order
+        if not self.collect_ep_infos:
+            return []
+        r = self.last_ep_returns.cpu().numpy()
+        l_ = self.last_ep_lengths.cpu().numpy()
         return [{"r": float(a), "l": int(b)} for a, b in zip(r, l_)]
 
     def run(self, noise=None):
@@ -167,7 +175,7 @@ class Runner:
         mb_advs, mb_returns = compute_gae(env, ro["rewards"], ro["values"], ro["dones"], ro["last_values"],
                                           ro["last_dones"], self.gamma, self.lam)          # ppo2.py:507-520
         ep_infos = []
-        if self.collect_ep_infos:
+        if self.track_episodes:
             done_after = t.cat([ro["dones"][1:], ro["last_dones"].view(1, -1)], 0).bool()
             ep_infos = self._episode_infos(ro["rewards"], done_after)
         self.obs, self.dones = ro["last_obs"], ro["last_dones"]

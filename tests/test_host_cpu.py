@@ -191,3 +191,58 @@ def test_vecenv_and_gym_method_surface():
         for m in ("reset", "step", "seed", "render", "close"):
             assert callable(getattr(cls, m)), (cls, m)
     assert qa.make.__doc__ and qa.shard_range(8, 0, 2) == (0, 4)
+
+
+def test_actor_critic_step_host_logic_matches_oracle():
+    """ActorCriticPolicy.step / value (the per-step API's model.step on torch) against the float64 restatement, plain
+    and tanh-squashed; the C struct handed to qs_runner_rollout mirrors include/quadsim.h"""
+    import torch
+    import quadsim_amd as qa
+    from quadsim_amd import _lib
+    from oracle.pyoracle import actor_critic_step
+    path = os.path.join(ROOT, "tests", "golden", "policy_best_model_v0.npz")
+    with np.load(path, allow_pickle=False) as z:
+        W = {k: z[k] for k in z.files}
+    rng = np.random.RandomState(0)
+    obs = (rng.randn(200, 12) * np.array([1, 1, 1, .5, .5, .5, .3, .3, .3, .5, .5, .5])).astype(np.float32)
+    noise = rng.randn(200, 4).astype(np.float32)
+    for squash in (False, True):
+        pol = qa.ActorCriticPolicy.from_npz(path, device="cpu", squash=squash)
+        u, v, st, nl = pol.step(torch.as_tensor(obs), noise=torch.as_tensor(noise))
+        ur, vr, nlr, ar, mean = actor_critic_step(W, obs, noise, squash)
+        np.testing.assert_allclose(u.numpy(), ur, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(v.numpy(), vr, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(nl.numpy(), nlr, rtol=1e-4, atol=2e-3)
+        np.testing.assert_allclose(pol.env_action(u).numpy(), ar, atol=1e-5)
+        assert st is None
+        ud = pol.step(torch.as_tensor(obs), deterministic=True)[0]
+        np.testing.assert_allclose(ud.numpy(), mean, rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(pol.value(torch.as_tensor(obs)).numpy(), vr, rtol=1e-5, atol=1e-5)
+    s = pol.c_struct()
+    assert s.struct_size == ctypes.sizeof(_lib.QsActorCritic) == 104 and s.squash == 1
+    np.testing.assert_allclose(list(s.logstd), W["logstd"], rtol=0, atol=0)
+
+
+def test_runner_episode_bookkeeping_across_runs():
+    """Runner._episode_infos: segmented episode returns / lengths over [T,N] tensors, carried across consecutive runs"""
+    import torch
+    from quadsim_amd.runner import Runner
+    rng = np.random.RandomState(4)
+    n, T = 37, 25
+    r = Runner.__new__(Runner)
+    r.torch = torch; r.collect_ep_infos = True
+    r._ep_ret = torch.zeros(n); r._ep_len = torch.zeros(n, dtype=torch.int64)
+    ep_ret = np.zeros(n); ep_len = np.zeros(n, np.int64)
+    for it in range(3):
+        rew = rng.randn(T, n).astype(np.float32)
+        done = rng.rand(T, n) < (0.0 if it == 1 else 0.1)          # run 1 has no episode end at all
+        got = r._episode_infos(torch.as_tensor(rew), torch.as_tensor(done))
+        want = []
+        for t in range(T):
+            ep_ret += rew[t]; ep_len += 1
+            for i in np.nonzero(done[t])[0]:
+                want.append((ep_ret[i], ep_len[i])); ep_ret[i] = 0.0; ep_len[i] = 0
+        assert [e["l"] for e in got] == [int(l_) for _, l_ in want]
+        np.testing.assert_allclose([e["r"] for e in got], [x for x, _ in want], atol=1e-4)
+        np.testing.assert_allclose(r._ep_ret.numpy(), ep_ret, atol=1e-4)
+        assert np.array_equal(r._ep_len.numpy(), ep_len)
