@@ -807,9 +807,11 @@ struct QsEnv {
     size_t gae_ws_floats = 0;
     float *init = nullptr;      // stored per-env initial states (docking-v1, hovering-v0, qs_set_init_state)
     int obs_dim = 12;
-    // staging for QS_IO_HOST
+    // staging for QS_IO_HOST: a device buffer plus a pinned, device-mapped host mirror of the same size
     void *stage = nullptr;
     size_t stage_bytes = 0;
+    char *hpin = nullptr;       // host address of the mirror
+    char *hpin_dev = nullptr;   // its device address (kernels of small batches read / write it in place)
 };
 
 namespace {
@@ -847,8 +849,13 @@ int ensure_stage(QsEnv *e, size_t bytes)
 {
     if (e->stage_bytes >= bytes) return QS_OK;
     if (e->stage) { HIP_TRY(hipStreamSynchronize(e->stream)); HIP_TRY(hipFree(e->stage)); e->stage = nullptr; e->stage_bytes = 0; }
+    if (e->hpin) { HIP_TRY(hipHostFree(e->hpin)); e->hpin = nullptr; e->hpin_dev = nullptr; }
     HIP_TRY(hipMalloc(&e->stage, bytes));
     e->stage_bytes = bytes;
+    if (e->cfg.io_space == QS_IO_HOST) {
+        HIP_TRY(hipHostMalloc((void **)&e->hpin, bytes, hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer((void **)&e->hpin_dev, e->hpin, 0));
+    }
     return QS_OK;
 }
 
@@ -861,6 +868,36 @@ struct Stage {
         T *p = reinterpret_cast<T *>(base + off);
         off += (count * sizeof(T) + 255) & ~size_t(255);
         return p;
+    }
+};
+
+// Host-buffer calls (QS_IO_HOST: the single-env gym shims, SB2-style numpy VecEnvs) bounce through the pinned mirror.
+// Up to kDirectBytes the kernels read and write the mapped host memory in place (a step of a few envs costs one
+// launch and one stream sync, no copy engine); larger blocks take ONE DMA in and ONE DMA out of the device buffer.
+// Slices are taken in the same order on both sides, so a device pointer maps to its host twin by offset.
+constexpr size_t kDirectBytes = 64u << 10;
+struct Bounce {
+    QsEnv *e;
+    bool direct;
+    char *dbase;
+    Stage S;
+    size_t in_end = 0;      // inputs occupy [0, in_end), outputs [in_end, S.off)
+    Bounce(QsEnv *env, size_t bytes)
+        : e(env), direct(bytes <= kDirectBytes), dbase(direct ? env->hpin_dev : (char *)env->stage), S{dbase} {}
+    template <typename T> T *take(size_t count) { return S.take<T>(count); }
+    template <typename T> T *host(T *dptr) const { return reinterpret_cast<T *>(e->hpin + ((char *)dptr - dbase)); }
+    void inputs_done() { in_end = S.off; }
+    int push()              // after the caller filled host(...) of every input slice
+    {
+        if (!direct && in_end) HIP_TRY(hipMemcpyAsync(dbase, e->hpin, in_end, hipMemcpyHostToDevice, e->stream));
+        return QS_OK;
+    }
+    int pull()              // after the kernels were enqueued: outputs land in host(...) of every output slice
+    {
+        if (!direct && S.off > in_end)
+            HIP_TRY(hipMemcpyAsync(e->hpin + in_end, dbase + in_end, S.off - in_end, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        return QS_OK;
     }
 };
 
@@ -1044,6 +1081,7 @@ int qs_destroy(QsEnv *e)
     if (e->d_ctr) (void)hipFree(e->d_ctr);
     if (e->gae_ws) (void)hipFree(e->gae_ws);
     if (e->stage) (void)hipFree(e->stage);
+    if (e->hpin) (void)hipHostFree(e->hpin);
     if (e->ev0) (void)hipEventDestroy(e->ev0);
     if (e->ev1) (void)hipEventDestroy(e->ev1);
     if (e->own_stream && e->stream) (void)hipStreamDestroy(e->stream);
@@ -1112,17 +1150,24 @@ int qs_reset(QsEnv *e, const uint8_t *mask, float *obs_out)
     const int64_t n = e->n;
     if (e->cfg.io_space == QS_IO_DEVICE) return do_reset(e, mask, obs_out, 0);
     const int64_t od = e->obs_dim;
-    int r = ensure_stage(e, (size_t)n * (od * 4 + 1) + 1024);
+    const size_t need = (size_t)n * (od * 4 + 1) + 1024;
+    int r = ensure_stage(e, need);
     if (r) return r;
-    Stage S{(char *)e->stage};
-    float *d_obs = S.take<float>(n * od);
-    uint8_t *d_mask = S.take<uint8_t>(n);
-    if (mask) HIP_TRY(hipMemcpyAsync(d_mask, mask, n, hipMemcpyHostToDevice, e->stream));
-    if (obs_out && mask) HIP_TRY(hipMemcpyAsync(d_obs, obs_out, n * od * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    Bounce B(e, need);
+    uint8_t *d_mask = B.take<uint8_t>(n);
+    B.inputs_done();
+    float *d_obs = B.take<float>(n * od);
+    if (mask) memcpy(B.host(d_mask), mask, n);
+    if (obs_out && mask) {
+        // rows of envs that are not reset keep the caller's values: seed the output slice with them
+        memcpy(B.host(d_obs), obs_out, n * od * sizeof(float));
+        if (!B.direct) HIP_TRY(hipMemcpyAsync(d_obs, B.host(d_obs), n * od * sizeof(float), hipMemcpyHostToDevice, e->stream));
+    }
+    if (mask && (r = B.push())) return r;
     r = do_reset(e, mask ? d_mask : nullptr, d_obs, 0);
     if (r) return r;
-    if (obs_out) HIP_TRY(hipMemcpyAsync(obs_out, d_obs, n * od * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-    HIP_TRY(hipStreamSynchronize(e->stream));
+    if ((r = B.pull())) return r;
+    if (obs_out) memcpy(obs_out, B.host(d_obs), n * od * sizeof(float));
     return QS_OK;
 }
 
@@ -1139,24 +1184,32 @@ int qs_step(QsEnv *e, const float *actions, float *obs, float *reward, uint8_t *
         if (r) return r;
     } else {
         const int64_t od = e->obs_dim;
-        r = ensure_stage(e, (size_t)n * (4 * 4 + od * 4 + 4 + 1 + 1 + od * 4) + 4096);
+        const size_t need = (size_t)n * (4 * 4 + od * 4 + 4 + 1 + 1 + od * 4) + 4096;
+        r = ensure_stage(e, need);
         if (r) return r;
-        Stage S{(char *)e->stage};
-        float *d_act = S.take<float>(n * 4), *d_obs = S.take<float>(n * od), *d_rew = S.take<float>(n);
-        uint8_t *d_done = S.take<uint8_t>(n), *d_flags = S.take<uint8_t>(n);
-        float *d_term = S.take<float>(n * od);
-        HIP_TRY(hipMemcpyAsync(d_act, actions, n * 4 * sizeof(float), hipMemcpyHostToDevice, e->stream));
-        if (terminal_obs) HIP_TRY(hipMemcpyAsync(d_term, terminal_obs, n * od * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        Bounce B(e, need);
+        float *d_act = B.take<float>(n * 4);
+        B.inputs_done();
+        float *d_obs = B.take<float>(n * od), *d_rew = B.take<float>(n);
+        uint8_t *d_done = B.take<uint8_t>(n), *d_flags = B.take<uint8_t>(n);
+        float *d_term = B.take<float>(n * od);
+        memcpy(B.host(d_act), actions, n * 4 * sizeof(float));
+        if ((r = B.push())) return r;
+        if (terminal_obs) {
+            // rows of envs that did not finish keep the caller's values
+            memcpy(B.host(d_term), terminal_obs, n * od * sizeof(float));
+            if (!B.direct) HIP_TRY(hipMemcpyAsync(d_term, B.host(d_term), n * od * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        }
         A.actions = d_act; A.obs = d_obs; A.reward = d_rew; A.done = d_done; A.flags = d_flags;
         A.term_obs = terminal_obs ? d_term : nullptr;
         r = launch_env(e, A);
         if (r) return r;
-        HIP_TRY(hipMemcpyAsync(obs, d_obs, n * od * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipMemcpyAsync(reward, d_rew, n * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipMemcpyAsync(done, d_done, n, hipMemcpyDeviceToHost, e->stream));
-        if (flags) HIP_TRY(hipMemcpyAsync(flags, d_flags, n, hipMemcpyDeviceToHost, e->stream));
-        if (terminal_obs) HIP_TRY(hipMemcpyAsync(terminal_obs, d_term, n * od * sizeof(float), hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        if ((r = B.pull())) return r;
+        memcpy(obs, B.host(d_obs), n * od * sizeof(float));
+        memcpy(reward, B.host(d_rew), n * sizeof(float));
+        memcpy(done, B.host(d_done), n);
+        if (flags) memcpy(flags, B.host(d_flags), n);
+        if (terminal_obs) memcpy(terminal_obs, B.host(d_term), n * od * sizeof(float));
     }
     return QS_OK;
 }
@@ -1254,27 +1307,31 @@ static int state_io(QsEnv *e, bool to_user, float *chaser, float *target, float 
     const int64_t words[6] = {13, 13, 8, 4, 1, 1};
     float *user[6] = {chaser, target, u_prev, qdes, ls, t};
     StateIO io{chaser, target, u_prev, qdes, ls, t};
-    float *dev[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    if (e->cfg.io_space == QS_IO_HOST) {
-        int r = ensure_stage(e, (size_t)n * 40 * 4 + 4096);
-        if (r) return r;
-        Stage S{(char *)e->stage};
-        for (int i = 0; i < 6; ++i) {
-            dev[i] = S.take<float>(n * words[i]);
-            if (user[i] && !to_user) HIP_TRY(hipMemcpyAsync(dev[i], user[i], n * words[i] * 4, hipMemcpyHostToDevice, e->stream));
-        }
-        io = StateIO{chaser ? dev[0] : nullptr, target ? dev[1] : nullptr, u_prev ? dev[2] : nullptr,
-                     qdes ? dev[3] : nullptr, ls ? dev[4] : nullptr, t ? dev[5] : nullptr};
+    if (e->cfg.io_space == QS_IO_DEVICE) {
+        if (to_user) hipLaunchKernelGGL(k_state_io<true>, dim3(grid_tiles(n)), dim3(kBlock), 0, e->stream, e->st, n, io);
+        else hipLaunchKernelGGL(k_state_io<false>, dim3(grid_tiles(n)), dim3(kBlock), 0, e->stream, e->st, n, io);
+        HIP_TRY(hipGetLastError());
+        return QS_OK;
     }
+    const size_t need = (size_t)n * 40 * 4 + 4096;
+    int r = ensure_stage(e, need);
+    if (r) return r;
+    Bounce B(e, need);
+    float *dev[6];
+    for (int i = 0; i < 6; ++i) {
+        dev[i] = B.take<float>(n * words[i]);
+        if (user[i] && !to_user) memcpy(B.host(dev[i]), user[i], n * words[i] * 4);
+    }
+    if (!to_user) { B.inputs_done(); if ((r = B.push())) return r; }
+    io = StateIO{chaser ? dev[0] : nullptr, target ? dev[1] : nullptr, u_prev ? dev[2] : nullptr,
+                 qdes ? dev[3] : nullptr, ls ? dev[4] : nullptr, t ? dev[5] : nullptr};
     if (to_user) hipLaunchKernelGGL(k_state_io<true>, dim3(grid_tiles(n)), dim3(kBlock), 0, e->stream, e->st, n, io);
     else hipLaunchKernelGGL(k_state_io<false>, dim3(grid_tiles(n)), dim3(kBlock), 0, e->stream, e->st, n, io);
     HIP_TRY(hipGetLastError());
-    if (e->cfg.io_space == QS_IO_HOST) {
-        if (to_user)
-            for (int i = 0; i < 6; ++i)
-                if (user[i]) HIP_TRY(hipMemcpyAsync(user[i], dev[i], n * words[i] * 4, hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
-    }
+    if ((r = B.pull())) return r;
+    if (to_user)
+        for (int i = 0; i < 6; ++i)
+            if (user[i]) memcpy(user[i], B.host(dev[i]), n * words[i] * 4);
     return QS_OK;
 }
 
