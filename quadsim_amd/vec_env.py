@@ -104,6 +104,7 @@ class VecDockingEnv:
         self._flags = torch.empty((n,), dtype=torch.uint8, **kw)
         self._term = torch.zeros((n, self.obs_dim), dtype=torch.float32, **kw)
         self._actions = None
+        self._pin, self._pin_i, self._act_pin = None, 0, None
         self.auto_reset = bool(auto_reset)
         # attribute surface the reference scripts poke (run_trained_docking_ppo2.py:45)
         self.action_mean = np.ones(4) * mass * 9.81 / 2.0
@@ -167,7 +168,17 @@ class VecDockingEnv:
 
     def step_async(self, actions):
         self._use_current_stream()
-        self._actions = self._as_device(actions, (self.num_envs, 4))
+        if self.backend == "numpy" and isinstance(actions, np.ndarray):
+            # host actions: through a pinned staging tensor, asynchronously (no pageable-memory copy on the way up)
+            torch = _torch()
+            if self._act_pin is None:
+                self._act_pin = torch.empty((self.num_envs, 4), dtype=torch.float32, pin_memory=True)
+                self._act_dev = torch.empty((self.num_envs, 4), dtype=torch.float32, device=self.device)
+            np.copyto(self._act_pin.numpy(), actions.reshape(self.num_envs, 4), casting="same_kind")
+            self._act_dev.copy_(self._act_pin, non_blocking=True)
+            self._actions = self._act_dev
+        else:
+            self._actions = self._as_device(actions, (self.num_envs, 4))
         _lib.check(self._lib.qs_step(self._h, self._ptr(self._actions), self._ptr(self._obs), self._ptr(self._rew),
                                      self._ptr(self._done), self._ptr(self._flags),
                                      self._ptr(self._term) if self.auto_reset else None), "qs_step")
@@ -176,8 +187,18 @@ class VecDockingEnv:
         if self.backend == "torch":
             # views of the env's own buffers (valid until the next step); done is the uint8 buffer seen as bool
             return self._obs, self._rew, self._done.view(_torch().bool), InfoView(self)
-        obs, rew = self._obs.cpu().numpy(), self._rew.cpu().numpy()
-        done, flags = self._done.cpu().numpy().astype(bool), self._flags.cpu().numpy()
+        # numpy backend: four async copies into pinned host mirrors, ONE stream sync.  Two sets of mirrors alternate,
+        # so the arrays of a step stay valid until the step after the next one (SB2's runner copies them at once).
+        torch = _torch()
+        if self._pin is None:
+            mk = lambda t: torch.empty(t.shape, dtype=t.dtype, pin_memory=True)                 # noqa: E731
+            self._pin = [[mk(t) for t in (self._obs, self._rew, self._done, self._flags)] for _ in range(2)]
+        self._pin_i ^= 1
+        h = self._pin[self._pin_i]
+        for dst, src in zip(h, (self._obs, self._rew, self._done, self._flags)):
+            dst.copy_(src, non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()
+        obs, rew, done, flags = h[0].numpy(), h[1].numpy(), h[2].numpy().view(np.bool_), h[3].numpy()
         infos = InfoView(self, done=done, flags=flags)
         return obs, rew, done, infos
 

@@ -1074,3 +1074,33 @@ def test_runner_run_matches_reference_bookkeeping(qa, oracle64):
         np.testing.assert_allclose([e["r"] for e in ep_infos], [r for r, _ in want], atol=2e-3)
     assert runner.num_timesteps == 2 * n * T
     env.close()
+
+
+def test_numpy_backend_matches_torch_backend(qa):
+    """VecDockingEnv(backend="numpy"), the SB2-facing host-array mode (pinned mirrors, one sync per step), returns
+    exactly what the torch backend returns; a step's arrays stay valid through the following step"""
+    n, seed = 300, 3
+    kw = dict(num_envs=n, randomise=1, seed=seed, init_range=qa.C3_INIT_RANGE)
+    et = qa.VecDockingEnv("docking-v0", **kw); en = qa.VecDockingEnv("docking-v0", backend="numpy", **kw)
+    ot, on = et.reset(), en.reset()
+    assert isinstance(on, np.ndarray) and on.dtype == np.float32 and on.shape == (n, 12)
+    assert np.array_equal(ot.cpu().numpy(), on)
+    acts = et.random_actions(60).cpu().numpy()
+    prev = None
+    n_done = 0
+    for k in range(60):
+        o1, r1, d1, i1 = et.step(et._as_device(acts[k], (n, 4)))
+        o2, r2, d2, i2 = en.step(acts[k])
+        assert o2.dtype == np.float32 and r2.dtype == np.float32 and d2.dtype == np.bool_ and len(i2) == n
+        assert np.array_equal(o1.cpu().numpy(), o2) and np.array_equal(r1.cpu().numpy(), r2)
+        assert np.array_equal(d1.cpu().numpy(), d2)
+        if prev is not None:
+            assert np.array_equal(prev[0], prev[1])            # last step's array was not overwritten by this step
+        prev = (o2, o2.copy())
+        if d2.any():
+            i = int(np.argmax(d2))
+            np.testing.assert_array_equal(i2[i]["terminal_observation"], i1[i]["terminal_observation"])
+            assert i2[i]["done_overlimit"] == i1[i]["done_overlimit"]
+            n_done += int(d2.sum())
+    assert n_done > 100
+    et.close(); en.close()
