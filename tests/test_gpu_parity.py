@@ -361,7 +361,17 @@ def test_errors_are_loud(qa):
         env.rollout(T=4)
     with pytest.raises(ValueError):
         env.step(np.zeros((7, 4), np.float32))
+    pol, _ = _ac_policy(qa)
+    with pytest.raises(_lib.QuadsimError, match="auto_reset"):
+        qa.fused_runner_rollout(env, pol, 2)                              # a Runner roll-out runs through episode ends
     env.close()
+    hov = qa.VecDockingEnv("hovering-v0", num_envs=8)
+    with pytest.raises(_lib.QuadsimError, match="docking"):
+        qa.fused_runner_rollout(hov, pol, 2)                              # the shipped networks are docking policies
+    bad = pol.c_struct(); bad.struct_size = 8
+    out = qa.VecDockingEnv("docking-v0", num_envs=8)
+    assert out._lib.qs_runner_rollout(out._h, 1, C.byref(bad), *([None] * 12)) == -1
+    hov.close(); out.close()
 
 
 def test_two_ranks_on_one_gpu_equal_one_handle(qa, tmp_path):
