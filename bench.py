@@ -275,20 +275,22 @@ def main():
             # neglogp + env.step for n_steps in one launch, then the GAE kernel and the env-major flatten of 7 arrays
             from quadsim_amd import ActorCriticPolicy, Runner
             ac = ActorCriticPolicy.from_npz(wpath, device="cuda:%d" % local_rank)
-            runner = Runner(env=env, model=ac, n_steps=Tp, gamma=0.99, lam=0.95, track_episodes=False)
-            runner.run()
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(4):
-                runner.run()
-            torch.cuda.synchronize()
-            w6 = max_over_ranks(time.perf_counter() - t0)
             flop_ac = 2 * (12 * 128 + 2 * 128 * 128 + 128 * 4 + 128)
-            out["ppo2_runner_f32_mfma"] = {
-                "value": total_envs * Tp * 4 / w6, "unit": "env-steps/s", "T": Tp,
-                "mlp_tflops": total_envs * (Tp + 1) * 4 * flop_ac / w6 / 1e12,
-                "what": "Runner.run(): qs_runner_rollout (policy + value nets on exact-f32 MFMA, rocRAND Gaussian sampling, "
-                        "neglogp, fused env.step) + qs_gae + swap_and_flatten of obs/returns/dones/actions/values/neglogp/rewards"}
+            for prec, key in (("f32", "ppo2_runner_f32_mfma"), ("bf16x3", "ppo2_runner_bf16x3_mfma")):
+                runner = Runner(env=env, model=ac, n_steps=Tp, gamma=0.99, lam=0.95, track_episodes=False, precision=prec)
+                runner.run()
+                barrier()
+                t0 = time.perf_counter()
+                for _ in range(4):
+                    runner.run()
+                torch.cuda.synchronize()
+                w6 = max_over_ranks(time.perf_counter() - t0)
+                out[key] = {"value": total_envs * Tp * 4 / w6, "unit": "env-steps/s", "T": Tp,
+                            "mlp_tflops": total_envs * (Tp + 1) * 4 * flop_ac / w6 / 1e12}
+            out["ppo2_runner_f32_mfma"]["what"] = (
+                "Runner.run(): qs_runner_rollout (policy + value nets on exact-f32 MFMA, rocRAND Gaussian sampling, "
+                "neglogp, fused env.step) + qs_gae + swap_and_flatten of obs/returns/dones/actions/values/neglogp/rewards")
+            out["ppo2_runner_bf16x3_mfma"]["note"] = "the same with split-bf16 operands (qs_runner_rollout_fast), ~1e-5 error on means / values (opt-in)"
         if distributed and args.backend == "nccl":
             # BASELINE configs 4/5: RCCL all-gather of the roll-out slabs (obs, reward, done) once per T-step roll-out
             from quadsim_amd.distributed import gather_slab

@@ -252,6 +252,16 @@ int qs_runner_rollout(QsEnv *env, int64_t T, const QsActorCritic *policy, const 
                       uint8_t *mb_dones /* [T,N] */, float *mb_rewards /* [T,N] */, uint8_t *mb_flags /* nullable [T,N] */,
                       float *last_obs /* nullable [N,12] */, float *last_values /* [N] */, uint8_t *last_dones /* [N] */);
 
+/* qs_runner_rollout with the networks on the bf16 matrix rate and split (hi + lo) operands, as qs_policy_rollout_fast:
+ * about 1e-5 error on means and values instead of float32's 1e-7; opt-in.  packed_weights: device image of
+ * qs_runner_rollout_fast_blob_bytes() bytes, 16-byte aligned (layout: quadsim_amd/csrc/policy_rollout.hpp "Fast
+ * actor-critic heads"; quadsim_amd.runner.pack_fast_actor_critic builds it); logstd [4] on the HOST. */
+int qs_runner_rollout_fast(QsEnv *env, int64_t T, const void *packed_weights, const float *logstd, int squash,
+                           const float *noise, const uint8_t *dones_in, float *mb_obs, float *mb_actions, float *mb_values,
+                           float *mb_neglogp, uint8_t *mb_dones, float *mb_rewards, uint8_t *mb_flags, float *last_obs,
+                           float *last_values, uint8_t *last_dones);
+int qs_runner_rollout_fast_blob_bytes(void);
+
 /* PID expert of run_expert_policy.py:49-69 / run_expert_record.py:121-136 for all N docking envs: from the handle's
  * current chaser / target states, des_vel = kp (p_target + (-0.2,0,0) - p_chaser) + kd (-v_chaser), vel_controller on
  * the chaser, action = (inv(rotor2control) u - action_mean) / action_std (not clipped).  state_des [N,13] in/out is

@@ -351,4 +351,130 @@ __device__ __forceinline__ void mlp_actor_fast(const float obs[12], float act[4]
     __builtin_amdgcn_wave_barrier();
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Fast actor-critic heads (qs_runner_rollout_fast): mlp_actor_critic with the two 128x128 layers and the output layer
+// on the bf16 matrix rate with split (hi + lo) operands, exactly as mlp_actor_fast; the 12-input first layer stays on
+// the f32 MFMA (96 MFMAs, and its f32 weights are a third of the size of split fragments padded to k = 32).
+// LDS image (bytes): A2pi hi 32768 | lo 32768 | A2vf hi 32768 | lo 32768 | A3pi hi 1024 | lo 1024 | A3vf hi 256 | lo 256 |
+// W1^T f32 128x13 6656 | b1 512 | b2pi 512 | b2vf 512 | b3 64 | per-wave stage 4 x 3072  = 154 176 B.
+// A3pi keeps only output rows 0..3, A3vf only row 4 of the 16-row tile: [k-step q][row][g][8 bf16] / [q][g][8 bf16].
+constexpr int kAcFastA2 = 0;
+constexpr int kAcFastA3p = 4 * 32768;
+constexpr int kAcFastA3v = kAcFastA3p + 2 * 1024;
+constexpr int kAcFastW1 = kAcFastA3v + 2 * 256;
+constexpr int kAcFastB = kAcFastW1 + kHid * kLdW1 * 4;
+constexpr int kAcFastBlobBytes = kAcFastB + (3 * kHid + 16) * 4;
+constexpr int kAcFastLdsBytes = kAcFastBlobBytes + 4 * (12 * 64) * 4;
+
+__device__ __forceinline__ void mlp_actor_critic_fast(const float obs[12], float out[5], const char *blob, float *stage,
+                                                      int lane)
+{
+    const float *sW1 = reinterpret_cast<const float *>(blob + kAcFastW1);
+    const float *sB1 = reinterpret_cast<const float *>(blob + kAcFastB);
+    const float *sB2p = sB1 + kHid, *sB2v = sB2p + kHid, *sB3 = sB2v + kHid;
+    const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+    for (int k = 0; k < 12; ++k) stage[k * 64 + lane] = obs[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // ---- layer 1 on the f32 MFMA, ReLU, straight into split B operands of layer 2 (tiles 2p, 2p+1 -> k-step p)
+    float xb[3][4];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int et = 0; et < 4; ++et) xb[s][et] = stage[(4 * s + g) * 64 + 16 * et + c];
+    bf16x8 bh[4][4], bl[4][4];      // [p][et]
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt) {
+        const f32x4 bias = *reinterpret_cast<const f32x4 *>(sB1 + 16 * rt + 4 * g);
+        float a[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) a[s] = sW1[(16 * rt + c) * kLdW1 + 4 * s + g];
+#pragma unroll
+        for (int et = 0; et < 4; ++et) {
+            f32x4 acc = bias;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], xb[s][et], acc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                __bf16 h, l;
+                split_bf16(fmaxf(acc[i], 0.0f), h, l);
+                bh[rt >> 1][et][4 * (rt & 1) + i] = h;
+                bl[rt >> 1][et][4 * (rt & 1) + i] = l;
+            }
+        }
+    }
+    f32x4 a3[4];
+    {
+        const f32x4 bias3 = *reinterpret_cast<const f32x4 *>(sB3 + 4 * g);
+#pragma unroll
+        for (int et = 0; et < 4; ++et) a3[et] = bias3;
+    }
+    const bf16x8 zero8 = {};
+#pragma unroll
+    for (int br = 0; br < 2; ++br) {                       // 0: policy branch -> rows 0..3, 1: value branch -> row 4
+        const bf16x8 *A2hi = reinterpret_cast<const bf16x8 *>(blob + kAcFastA2 + br * 65536);
+        const bf16x8 *A2lo = reinterpret_cast<const bf16x8 *>(blob + kAcFastA2 + br * 65536 + 32768);
+        const float *sB2 = br ? sB2v : sB2p;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {                      // pair of layer-2 row tiles = k-step of the output layer
+            bf16x8 ch[4], cl[4];
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                const int nt = 2 * q + half;
+                const f32x4 bias = *reinterpret_cast<const f32x4 *>(sB2 + 16 * nt + 4 * g);
+                f32x4 h2[4] = {bias, bias, bias, bias};
+#pragma unroll
+                for (int p = 0; p < 4; ++p) {
+                    const bf16x8 ah = A2hi[(nt * 4 + p) * 64 + lane], al = A2lo[(nt * 4 + p) * 64 + lane];
+#pragma unroll
+                    for (int et = 0; et < 4; ++et) {
+                        h2[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[p][et], h2[et], 0, 0, 0);
+                        h2[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[p][et], h2[et], 0, 0, 0);
+                        h2[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[p][et], h2[et], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int et = 0; et < 4; ++et)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        __bf16 h, l;
+                        split_bf16(fmaxf(h2[et][i], 0.0f), h, l);
+                        ch[et][4 * half + i] = h;
+                        cl[et][4 * half + i] = l;
+                    }
+            }
+            bf16x8 wh = zero8, wl = zero8;
+            if (br == 0) {
+                if (c < 4) {
+                    wh = reinterpret_cast<const bf16x8 *>(blob + kAcFastA3p)[(q * 4 + c) * 4 + g];
+                    wl = reinterpret_cast<const bf16x8 *>(blob + kAcFastA3p + 1024)[(q * 4 + c) * 4 + g];
+                }
+            } else if (c == 4) {
+                wh = reinterpret_cast<const bf16x8 *>(blob + kAcFastA3v)[q * 4 + g];
+                wl = reinterpret_cast<const bf16x8 *>(blob + kAcFastA3v + 256)[q * 4 + g];
+            }
+#pragma unroll
+            for (int et = 0; et < 4; ++et) {
+                a3[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ch[et], a3[et], 0, 0, 0);
+                a3[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, cl[et], a3[et], 0, 0, 0);
+                a3[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ch[et], a3[et], 0, 0, 0);
+            }
+        }
+    }
+    if (g == 0) {
+#pragma unroll
+        for (int et = 0; et < 4; ++et) *reinterpret_cast<f32x4 *>(stage + (16 * et + c) * 8) = a3[et];
+    } else if (g == 1) {
+#pragma unroll
+        for (int et = 0; et < 4; ++et) stage[(16 * et + c) * 8 + 4] = a3[et][0];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const f32x4 av = *reinterpret_cast<const f32x4 *>(stage + lane * 8);
+    out[0] = av[0]; out[1] = av[1]; out[2] = av[2]; out[3] = av[3];
+    out[4] = stage[lane * 8 + 4];
+    __builtin_amdgcn_wave_barrier();
+}
+
 }  // namespace qs

@@ -324,6 +324,7 @@ struct RunnerArgs {
     int squash;
     const float *noise;        // nullable [T,N,4]
     const uint8_t *dones_in;   // nullable [N]: done flags carried over from the previous run
+    const uint4 *blob;         // FAST only: packed split-bf16 weight image (kAcFastBlobBytes)
     float *actions;            // [T,N,4]
     float *values;             // [T,N]
     float *neglogp;            // [T,N]
@@ -332,31 +333,40 @@ struct RunnerArgs {
     uint8_t *last_dones;       // [N]
 };
 
-template <int INTEG, int RMODE>
+// FAST: the networks on the bf16 matrix rate with split operands (mlp_actor_critic_fast; R.blob = host-packed image)
+template <int INTEG, int RMODE, bool FAST>
 __global__ __launch_bounds__(kBlock, 1) void k_runner_rollout(StepArgs A, RunnerArgs R)
 {
-    __shared__ __attribute__((aligned(16))) float lds[ac_lds_floats()];
-    float *sW2p = lds;
-    float *sW2v = sW2p + kHid * kLdW;
-    float *sW3p = sW2v + kHid * kLdW;
-    float *sW3v = sW3p + 4 * kLdW;
-    float *sW1 = sW3v + kLdW;
-    float *sB1 = sW1 + kHid * kLdW1;
-    float *sB2p = sB1 + kHid;
-    float *sB2v = sB2p + kHid;
-    float *sB3 = sB2v + kHid;
-    float *sStage = sB3 + 16;
-    for (int i = threadIdx.x; i < kHid * kHid; i += kBlock) {
-        sW2p[(i >> 7) * kLdW + (i & 127)] = R.net.wt2[i];
-        sW2v[(i >> 7) * kLdW + (i & 127)] = R.net.wtv2[i];
+    __shared__ __attribute__((aligned(16))) char lds_raw[FAST ? kAcFastLdsBytes : (int)(ac_lds_floats() * sizeof(float))];
+    float *lds = reinterpret_cast<float *>(lds_raw);
+    AcLds L{};
+    float *sStage;
+    if (FAST) {
+        for (int i = threadIdx.x; i < kAcFastBlobBytes / 16; i += kBlock) reinterpret_cast<uint4 *>(lds_raw)[i] = R.blob[i];
+        sStage = reinterpret_cast<float *>(lds_raw + kAcFastBlobBytes);
+    } else {
+        float *sW2p = lds;
+        float *sW2v = sW2p + kHid * kLdW;
+        float *sW3p = sW2v + kHid * kLdW;
+        float *sW3v = sW3p + 4 * kLdW;
+        float *sW1 = sW3v + kLdW;
+        float *sB1 = sW1 + kHid * kLdW1;
+        float *sB2p = sB1 + kHid;
+        float *sB2v = sB2p + kHid;
+        float *sB3 = sB2v + kHid;
+        sStage = sB3 + 16;
+        for (int i = threadIdx.x; i < kHid * kHid; i += kBlock) {
+            sW2p[(i >> 7) * kLdW + (i & 127)] = R.net.wt2[i];
+            sW2v[(i >> 7) * kLdW + (i & 127)] = R.net.wtv2[i];
+        }
+        for (int i = threadIdx.x; i < 4 * kHid; i += kBlock) sW3p[(i >> 7) * kLdW + (i & 127)] = R.net.wt3[i];
+        for (int i = threadIdx.x; i < kHid; i += kBlock) sW3v[i] = R.net.wtv3[i];
+        for (int i = threadIdx.x; i < kHid * 12; i += kBlock) sW1[(i / 12) * kLdW1 + (i % 12)] = R.net.wt1[i];
+        for (int i = threadIdx.x; i < kHid; i += kBlock) { sB1[i] = R.net.b1[i]; sB2p[i] = R.net.b2[i]; sB2v[i] = R.net.bv2[i]; }
+        if (threadIdx.x < 16) sB3[threadIdx.x] = threadIdx.x < 4 ? R.net.b3[threadIdx.x] : (threadIdx.x == 4 ? R.net.bv3[0] : 0.0f);
+        L = AcLds{sW1, sB1, sW2p, sB2p, sW2v, sB2v, sW3p, sW3v, sB3};
     }
-    for (int i = threadIdx.x; i < 4 * kHid; i += kBlock) sW3p[(i >> 7) * kLdW + (i & 127)] = R.net.wt3[i];
-    for (int i = threadIdx.x; i < kHid; i += kBlock) sW3v[i] = R.net.wtv3[i];
-    for (int i = threadIdx.x; i < kHid * 12; i += kBlock) sW1[(i / 12) * kLdW1 + (i % 12)] = R.net.wt1[i];
-    for (int i = threadIdx.x; i < kHid; i += kBlock) { sB1[i] = R.net.b1[i]; sB2p[i] = R.net.b2[i]; sB2v[i] = R.net.bv2[i]; }
-    if (threadIdx.x < 16) sB3[threadIdx.x] = threadIdx.x < 4 ? R.net.b3[threadIdx.x] : (threadIdx.x == 4 ? R.net.bv3[0] : 0.0f);
     __syncthreads();
-    const AcLds L{sW1, sB1, sW2p, sB2p, sW2v, sB2v, sW3p, sW3v, sB3};
 
     const int lane = threadIdx.x & (kTile - 1);
     const int w = threadIdx.x >> 6;
@@ -377,7 +387,8 @@ __global__ __launch_bounds__(kBlock, 1) void k_runner_rollout(StepArgs A, Runner
         const int64_t o = t * A.n + env;
         if (active) store_obs(A.obs, o, obs);                         // mb_obs: the observation the policy acts on
         float head[5];
-        mlp_actor_critic(obs, head, L, stage, lane);
+        if (FAST) mlp_actor_critic_fast(obs, head, lds_raw, stage, lane);
+        else mlp_actor_critic(obs, head, L, stage, lane);
         float eps[4];
         if (R.noise) {
             const float4 nv = active ? reinterpret_cast<const float4 *>(R.noise)[o] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -422,7 +433,8 @@ __global__ __launch_bounds__(kBlock, 1) void k_runner_rollout(StepArgs A, Runner
     }
     // last_values = model.value(obs) on the observation after the last step (ppo2.py:506)
     float head[5];
-    mlp_actor_critic(obs, head, L, stage, lane);
+    if (FAST) mlp_actor_critic_fast(obs, head, lds_raw, stage, lane);
+    else mlp_actor_critic(obs, head, L, stage, lane);
     if (active) {
         R.last_values[env] = head[4];
         R.last_dones[env] = done_prev ? 1 : 0;
@@ -1546,47 +1558,78 @@ int qs_policy_rollout_fast(QsEnv *e, int64_t T, const void *packed_weights, floa
 
 int qs_policy_rollout_fast_blob_bytes(void) { return kFastBlobBytes; }
 
-int qs_runner_rollout(QsEnv *e, int64_t T, const QsActorCritic *pol, const float *noise, const uint8_t *dones_in,
-                      float *mb_obs, float *mb_actions, float *mb_values, float *mb_neglogp, uint8_t *mb_dones,
-                      float *mb_rewards, uint8_t *mb_flags, float *last_obs, float *last_values, uint8_t *last_dones)
+static int runner_launch(QsEnv *e, const char *who, int64_t T, const float logstd[4], int squash, const AcArgs *net,
+                         const void *blob, const float *noise, const uint8_t *dones_in, float *mb_obs, float *mb_actions,
+                         float *mb_values, float *mb_neglogp, uint8_t *mb_dones, float *mb_rewards, uint8_t *mb_flags,
+                         float *last_obs, float *last_values, uint8_t *last_dones)
 {
-    CHECK_ENV(e);
-    if (T < 1 || !pol || !mb_obs || !mb_actions || !mb_values || !mb_neglogp || !mb_dones || !mb_rewards || !last_values
-        || !last_dones)
-        return fail(QS_ERR_INVALID, "qs_runner_rollout: bad arguments");
-    if (pol->struct_size != sizeof(QsActorCritic)) return fail(QS_ERR_INVALID, "qs_runner_rollout: QsActorCritic.struct_size mismatch");
-    if (!pol->wt1 || !pol->b1 || !pol->wt2 || !pol->b2 || !pol->wt3 || !pol->b3 || !pol->wtv2 || !pol->bv2 || !pol->wtv3 || !pol->bv3)
-        return fail(QS_ERR_INVALID, "qs_runner_rollout: null weight pointer");
-    if (e->cfg.io_space != QS_IO_DEVICE) return fail(QS_ERR_INVALID, "qs_runner_rollout: device buffers only");
-    if (!e->cfg.auto_reset) return fail(QS_ERR_INVALID, "qs_runner_rollout: requires auto_reset");
+    if (T < 1 || !mb_obs || !mb_actions || !mb_values || !mb_neglogp || !mb_dones || !mb_rewards || !last_values || !last_dones)
+        return fail(QS_ERR_INVALID, "%s: bad arguments", who);
+    if (e->cfg.io_space != QS_IO_DEVICE) return fail(QS_ERR_INVALID, "%s: device buffers only", who);
+    if (!e->cfg.auto_reset) return fail(QS_ERR_INVALID, "%s: requires auto_reset", who);
     if (e->cfg.kind == QS_KIND_HOVERING_V0 || e->per_env_params || e->init || e->cfg.randomise > 1)
-        return fail(QS_ERR_INVALID, "qs_runner_rollout: docking-v0/v2 with nominal or rocRAND-initialised resets only");
+        return fail(QS_ERR_INVALID, "%s: docking-v0/v2 with nominal or rocRAND-initialised resets only", who);
     StepArgs A = make_args(e);
     A.T = T; A.obs = mb_obs; A.reward = mb_rewards; A.done = mb_dones; A.flags = mb_flags;
     RunnerArgs R{};
-    R.net = AcArgs{pol->wt1, pol->b1, pol->wt2, pol->b2, pol->wt3, pol->b3, pol->wtv2, pol->bv2, pol->wtv3, pol->bv3};
+    if (net) R.net = *net;
+    R.blob = (const uint4 *)blob;
     double ls = 0.0;
     for (int i = 0; i < 4; ++i) {
-        if (!(pol->logstd[i] == pol->logstd[i])) return fail(QS_ERR_INVALID, "qs_runner_rollout: logstd is NaN");
-        R.std[i] = expf(pol->logstd[i]);
+        if (!(logstd[i] == logstd[i])) return fail(QS_ERR_INVALID, "%s: logstd is NaN", who);
+        R.std[i] = expf(logstd[i]);
         R.inv_std[i] = 1.0f / R.std[i];
-        ls += (double)pol->logstd[i];
+        ls += (double)logstd[i];
     }
     R.nl_const = (float)(0.5 * 1.8378770664093453 * 4.0 + ls);      // 0.5 log(2 pi) d + sum logstd
-    R.squash = pol->squash;
+    R.squash = squash;
     R.noise = noise; R.dones_in = dones_in;
     R.actions = mb_actions; R.values = mb_values; R.neglogp = mb_neglogp;
     R.last_obs = last_obs; R.last_values = last_values; R.last_dones = last_dones;
     const unsigned grid = grid_tiles(e->n);
     const bool fr = e->cfg.integrator == QS_INTEG_FROZEN;
     const int rm = e->cfg.randomise;
-    if (fr && rm == 0) hipLaunchKernelGGL((k_runner_rollout<0, 0>), dim3(grid), dim3(kBlock), 0, e->stream, A, R);
-    else if (fr) hipLaunchKernelGGL((k_runner_rollout<0, 1>), dim3(grid), dim3(kBlock), 0, e->stream, A, R);
-    else if (rm == 0) hipLaunchKernelGGL((k_runner_rollout<1, 0>), dim3(grid), dim3(kBlock), 0, e->stream, A, R);
-    else hipLaunchKernelGGL((k_runner_rollout<1, 1>), dim3(grid), dim3(kBlock), 0, e->stream, A, R);
+#define QS_RUNNER_LAUNCH(FAST)                                                                                          \
+    do {                                                                                                                \
+        if (fr && rm == 0) hipLaunchKernelGGL((k_runner_rollout<0, 0, FAST>), dim3(grid), dim3(kBlock), 0, e->stream, A, R); \
+        else if (fr) hipLaunchKernelGGL((k_runner_rollout<0, 1, FAST>), dim3(grid), dim3(kBlock), 0, e->stream, A, R);  \
+        else if (rm == 0) hipLaunchKernelGGL((k_runner_rollout<1, 0, FAST>), dim3(grid), dim3(kBlock), 0, e->stream, A, R); \
+        else hipLaunchKernelGGL((k_runner_rollout<1, 1, FAST>), dim3(grid), dim3(kBlock), 0, e->stream, A, R);          \
+    } while (0)
+    if (blob) QS_RUNNER_LAUNCH(true);
+    else QS_RUNNER_LAUNCH(false);
+#undef QS_RUNNER_LAUNCH
     HIP_TRY(hipGetLastError());
     return QS_OK;
 }
+
+int qs_runner_rollout(QsEnv *e, int64_t T, const QsActorCritic *pol, const float *noise, const uint8_t *dones_in,
+                      float *mb_obs, float *mb_actions, float *mb_values, float *mb_neglogp, uint8_t *mb_dones,
+                      float *mb_rewards, uint8_t *mb_flags, float *last_obs, float *last_values, uint8_t *last_dones)
+{
+    CHECK_ENV(e);
+    if (!pol) return fail(QS_ERR_INVALID, "qs_runner_rollout: bad arguments");
+    if (pol->struct_size != sizeof(QsActorCritic)) return fail(QS_ERR_INVALID, "qs_runner_rollout: QsActorCritic.struct_size mismatch");
+    if (!pol->wt1 || !pol->b1 || !pol->wt2 || !pol->b2 || !pol->wt3 || !pol->b3 || !pol->wtv2 || !pol->bv2 || !pol->wtv3 || !pol->bv3)
+        return fail(QS_ERR_INVALID, "qs_runner_rollout: null weight pointer");
+    const AcArgs net{pol->wt1, pol->b1, pol->wt2, pol->b2, pol->wt3, pol->b3, pol->wtv2, pol->bv2, pol->wtv3, pol->bv3};
+    return runner_launch(e, "qs_runner_rollout", T, pol->logstd, pol->squash, &net, nullptr, noise, dones_in, mb_obs, mb_actions,
+                         mb_values, mb_neglogp, mb_dones, mb_rewards, mb_flags, last_obs, last_values, last_dones);
+}
+
+int qs_runner_rollout_fast(QsEnv *e, int64_t T, const void *packed_weights, const float *logstd, int squash, const float *noise,
+                           const uint8_t *dones_in, float *mb_obs, float *mb_actions, float *mb_values, float *mb_neglogp,
+                           uint8_t *mb_dones, float *mb_rewards, uint8_t *mb_flags, float *last_obs, float *last_values,
+                           uint8_t *last_dones)
+{
+    CHECK_ENV(e);
+    if (!packed_weights || !logstd) return fail(QS_ERR_INVALID, "qs_runner_rollout_fast: bad arguments");
+    if (((uintptr_t)packed_weights & 15) != 0) return fail(QS_ERR_INVALID, "qs_runner_rollout_fast: packed weights must be 16-byte aligned");
+    return runner_launch(e, "qs_runner_rollout_fast", T, logstd, squash, nullptr, packed_weights, noise, dones_in, mb_obs,
+                         mb_actions, mb_values, mb_neglogp, mb_dones, mb_rewards, mb_flags, last_obs, last_values, last_dones);
+}
+
+int qs_runner_rollout_fast_blob_bytes(void) { return kAcFastBlobBytes; }
 
 int qs_expert_action(QsEnv *e, float *state_des, float kp, float kd, float *actions)
 {

@@ -86,11 +86,55 @@ class ActorCriticPolicy:
         return s
 
 
-def fused_runner_rollout(env, policy, T, noise=None, dones_in=None, want_flags=False):
+def pack_fast_actor_critic(policy):
+    """Weight image of qs_runner_rollout_fast (csrc/policy_rollout.hpp, 'Fast actor-critic heads'): the two 128x128
+    layers and the output rows as ready-made split-bf16 A fragments in the k-order of the accumulator-as-B-operand
+    chaining, the first layer and the biases in float32."""
+    from .policy import _bf16_bits, _bf16_to_f32
+    g = lambda t: t.detach().cpu().numpy().astype(np.float32)                          # noqa: E731
+    w1t = g(policy.w0).T.copy()                       # [128][12]
+    lane = np.arange(64); gg, c = lane >> 4, lane & 15
+    j = np.arange(8)
+    hid = lambda p: 16 * (2 * p + (j[None, :] >> 2)) + 4 * gg[:, None] + (j[None, :] & 3)      # noqa: E731  [lane][j]
+
+    def split(a):
+        hi = _bf16_bits(a)
+        return hi.tobytes(), _bf16_bits(a - _bf16_to_f32(hi)).tobytes()
+
+    parts = []
+    for w in (policy.w1, policy.wv1):                 # A2 of the policy branch, then of the value branch
+        wt = g(w).T                                   # [out][in]
+        a2 = np.zeros((8, 4, 64, 8), np.float32)
+        for nt in range(8):
+            for p in range(4):
+                a2[nt, p] = wt[(16 * nt + c)[:, None], hid(p)]
+        parts += list(split(a2))
+    g4 = np.arange(4)
+    hid4 = lambda q: 16 * (2 * q + (j[None, :] >> 2)) + 4 * g4[:, None] + (j[None, :] & 3)     # noqa: E731  [g][j]
+    w3t = g(policy.w2).T                              # [4][128]
+    a3p = np.zeros((4, 4, 4, 8), np.float32)          # [q][row][g][j]
+    for q in range(4):
+        for r in range(4):
+            a3p[q, r] = w3t[r][hid4(q)]
+    parts += list(split(a3p))
+    wv3 = g(policy.wv2)[:, 0]                         # [128]
+    a3v = np.zeros((4, 4, 8), np.float32)             # [q][g][j]
+    for q in range(4):
+        a3v[q] = wv3[hid4(q)]
+    parts += list(split(a3v))
+    w1 = np.zeros((128, 13), np.float32); w1[:, :12] = w1t
+    b3 = np.zeros(16, np.float32); b3[:4] = g(policy.b2); b3[4] = g(policy.bv2)[0]
+    parts += [w1.tobytes(), g(policy.b0).tobytes(), g(policy.b1).tobytes(), g(policy.bv1).tobytes(), b3.tobytes()]
+    return np.frombuffer(b"".join(parts), np.uint8)
+
+
+def fused_runner_rollout(env, policy, T, noise=None, dones_in=None, want_flags=False, precision="f32"):
     """qs_runner_rollout: T Runner steps for all envs in one launch, from the envs' current state.
     -> dict of device tensors: obs [T,N,12] (the observations acted on), actions [T,N,4] (un-clipped samples),
     values, neglogp, rewards [T,N] f32, dones [T,N] u8 (flags BEFORE each step), flags [T,N] u8 or None,
-    last_obs [N,12], last_values [N], last_dones [N] u8."""
+    last_obs [N,12], last_values [N], last_dones [N] u8.
+    precision "f32": exact-float32 MFMA; "bf16x3": qs_runner_rollout_fast, split-bf16 operands on the bf16 matrix
+    rate, ~1e-5 error on means / values (opt-in)."""
     import torch
     n, dev = env.num_envs, env.device
     f32, u8 = torch.float32, torch.uint8
@@ -110,11 +154,21 @@ def fused_runner_rollout(env, policy, T, noise=None, dones_in=None, want_flags=F
         dones_in = dones_in.to(device=dev).to(u8).contiguous()
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None      # noqa: E731
     env._use_current_stream()
-    pol = policy.c_struct()
-    _lib.check(env._lib.qs_runner_rollout(env._h, T, C.byref(pol), p(noise), p(dones_in), p(out["obs"]), p(out["actions"]),
-                                          p(out["values"]), p(out["neglogp"]), p(out["dones"]), p(out["rewards"]),
-                                          p(out["flags"]), p(out["last_obs"]), p(out["last_values"]), p(out["last_dones"])),
-               "qs_runner_rollout")
+    tail = (p(noise), p(dones_in), p(out["obs"]), p(out["actions"]), p(out["values"]), p(out["neglogp"]), p(out["dones"]),
+            p(out["rewards"]), p(out["flags"]), p(out["last_obs"]), p(out["last_values"]), p(out["last_dones"]))
+    if precision == "f32":
+        pol = policy.c_struct()
+        _lib.check(env._lib.qs_runner_rollout(env._h, T, C.byref(pol), *tail), "qs_runner_rollout")
+    elif precision == "bf16x3":
+        if getattr(policy, "_ac_blob", None) is None:
+            blob = pack_fast_actor_critic(policy)
+            assert blob.size == env._lib.qs_runner_rollout_fast_blob_bytes()
+            policy._ac_blob = torch.as_tensor(blob.copy()).to(dev)
+        ls = (C.c_float * 4)(*[float(x) for x in policy.logstd_host])
+        _lib.check(env._lib.qs_runner_rollout_fast(env._h, T, p(policy._ac_blob), ls, 1 if policy.squash else 0, *tail),
+                   "qs_runner_rollout_fast")
+    else:
+        raise ValueError("precision must be 'f32' or 'bf16x3'")
     return out
 
 
@@ -128,11 +182,12 @@ class Runner:
     prefer ``collect_ep_infos=False`` and read the device tensors ``last_ep_returns`` / ``last_ep_lengths``."""
 
     def __init__(self, *, env, model, n_steps, gamma, lam, reset_after_run=False, collect_ep_infos=True,
-                 track_episodes=True):
+                 track_episodes=True, precision="f32"):
         import torch
         self.torch = torch
         self.env, self.model, self.n_steps, self.gamma, self.lam = env, model, int(n_steps), float(gamma), float(lam)
         self.reset_after_run = reset_after_run
+        self.precision = precision                     # "f32" | "bf16x3" (fused_runner_rollout)
         self.collect_ep_infos = collect_ep_infos       # build the reference's list of {'r', 'l'} dicts on the host
         self.track_episodes = track_episodes           # keep episode returns / lengths at all (device tensors
         self.last_ep_returns = self.last_ep_lengths = None   # last_ep_returns / last_ep_lengths after each run)
@@ -170,7 +225,7 @@ class Runner:
         t = self.torch
         env, T = self.env, self.n_steps
         mb_states = self.states
-        ro = fused_runner_rollout(env, self.model, T, noise=noise, dones_in=self.dones)
+        ro = fused_runner_rollout(env, self.model, T, noise=noise, dones_in=self.dones, precision=self.precision)
         self.num_timesteps += T * env.num_envs
         mb_advs, mb_returns = compute_gae(env, ro["rewards"], ro["values"], ro["dones"], ro["last_values"],
                                           ro["last_dones"], self.gamma, self.lam)          # ppo2.py:507-520

@@ -1114,3 +1114,34 @@ def test_numpy_backend_matches_torch_backend(qa):
             n_done += int(d2.sum())
     assert n_done > 100
     et.close(); en.close()
+
+
+def test_runner_rollout_fast_split_bf16(qa):
+    """qs_runner_rollout_fast (actor + critic on the bf16 matrix rate, split operands): opt-in precision -- means,
+    values and neglogp within 1e-4 of the exact-float32 runner on identical observations / noise, plain and squashed;
+    bookkeeping identical; a different evaluation (not the f32 path)"""
+    import torch
+    for squash in (False, True):
+        pol, _ = _ac_policy(qa, squash)
+        n, T = 3000, 24
+        kw = dict(num_envs=n, randomise=1, seed=5, init_range=qa.C3_INIT_RANGE)
+        e1 = qa.VecDockingEnv("docking-v0", **kw); e2 = qa.VecDockingEnv("docking-v0", **kw)
+        e1.reset(); e2.reset()
+        e1.set_state(t=np.full(n, 590.0, np.float32)); e2.set_state(t=np.full(n, 590.0, np.float32))
+        noise = torch.randn((T, n, 4), generator=torch.Generator().manual_seed(2))
+        a = {k: v.cpu().numpy() for k, v in qa.fused_runner_rollout(e1, pol, T, noise=noise).items() if v is not None}
+        b = {k: v.cpu().numpy() for k, v in qa.fused_runner_rollout(e2, pol, T, noise=noise, precision="bf16x3").items()
+             if v is not None}
+        # step 0: identical observations -> heads agree up to the split error
+        assert np.array_equal(a["obs"][0], b["obs"][0])
+        err_a = np.abs(a["actions"][0] - b["actions"][0]).max()
+        err_v = (np.abs(a["values"][0] - b["values"][0]) / (1.0 + np.abs(a["values"][0]))).max()    # values reach |v| ~ 10
+        assert 0.0 < err_a < 1e-4 and 0.0 < err_v < 5e-5, (err_a, err_v)
+        np.testing.assert_allclose(b["neglogp"][0], a["neglogp"][0], rtol=1e-4, atol=2e-3)
+        # whole roll-out: same episode bookkeeping, trajectories stay together
+        assert np.array_equal(a["dones"], b["dones"]) and a["dones"][10].all() and np.array_equal(a["last_dones"], b["last_dones"])
+        np.testing.assert_allclose(b["obs"], a["obs"], rtol=2e-3, atol=2e-3)
+        np.testing.assert_allclose(b["values"], a["values"], rtol=2e-3, atol=2e-3)
+        np.testing.assert_allclose(b["rewards"], a["rewards"], atol=5e-3)
+        np.testing.assert_allclose(b["last_values"], a["last_values"], rtol=2e-3, atol=2e-3)
+        e1.close(); e2.close()
