@@ -1145,3 +1145,31 @@ def test_runner_rollout_fast_split_bf16(qa):
         np.testing.assert_allclose(b["rewards"], a["rewards"], atol=5e-3)
         np.testing.assert_allclose(b["last_values"], a["last_values"], rtol=2e-3, atol=2e-3)
         e1.close(); e2.close()
+
+
+def test_baseline_config2_rk4_dt001_vs_oracle(qa):
+    """BASELINE config 2 as written: 4 096 docking-v0 envs, random actions, fp32 RK4 with dt = 0.01 -- single-step
+    parity against the oracle's RK4 from the HIP path's own pre-step state (rk4 has no counterpart in the reference:
+    parity-unpinned, HIP-vs-oracle only), plus the frozen integrator at the same dt"""
+    n = 4096
+    for integ, icode in (("rk4", 1), ("frozen", 0)):
+        env = qa.VecDockingEnv("docking-v0", num_envs=n, integrator=integ, dt=0.01, randomise=1, seed=2,
+                               init_range=qa.C3_INIT_RANGE)
+        env.reset()
+        orc = Oracle("f64")
+        rr = tuple(qa.C3_INIT_RANGE) + (1, 1, 1, 1)
+        for k in range(12):
+            rec = state_to_rec(env.get_state()); par = tile_par(n)
+            a = env.random_actions(1)[0]
+            kk = env.step_counter
+            obs, rew, done, _ = env.step(a)
+            obs, rew, done = obs.cpu().numpy(), rew.cpu().numpy(), done.cpu().numpy()
+            o, r, d, f, term = orc.vec_step(rec, par, a.cpu().numpy(), kind=0, dt=0.01, integ=icode, randomise=1, seed=2,
+                                            step_idx=kk, rr=rr, want_term=True)
+            t_obs = np.where(d[:, None].astype(bool), term, o)
+            safe = threshold_margin(t_obs, np.where(d.astype(bool), 1.0, rec[:, 2]), rec[:, 39], 3.0) > 1e-4
+            assert safe.mean() > 0.98 and np.array_equal(done[safe], d[safe].astype(bool))
+            np.testing.assert_allclose(obs[safe], o[safe], **OBS_TOL)
+            assert np.all(np.abs(rew[safe] - r[safe]) <= reward_atol(rec[safe, 38]) + reward_atol(r[safe]))
+            np.testing.assert_allclose(state_to_rec(env.get_state())[safe][:, :38], rec[safe][:, :38], **STATE_TOL)
+        env.close()
