@@ -235,7 +235,8 @@ int qs_policy_rollout_fast_blob_bytes(void);
  * through Box-Muller.  squash != 0 selects the fork's tanh variant (policies.py:238-242, distributions.py:412-415):
  * the env receives tanh(u), mb_neglogp adds sum(log(1 - tanh(u)^2 + 1e-6)), mb_actions keeps u.
  * Weights are TRANSPOSED (out, in) row-major float32 DEVICE arrays; logstd is read on the HOST.  The networks run on
- * the matrix cores in exact float32 (v_mfma_f32_16x16x4_f32).  docking-v0/v2, auto_reset, randomise 0/1, device I/O. */
+ * the matrix cores in exact float32 (v_mfma_f32_16x16x4_f32).  docking-v0/v2, auto_reset, any randomise mode (per-env
+ * mass / inertia and their per-episode redraw included: domain-randomised collection, BASELINE config 5), device I/O. */
 typedef struct QsActorCritic {
     uint32_t struct_size;       /* sizeof(QsActorCritic) */
     int32_t squash;

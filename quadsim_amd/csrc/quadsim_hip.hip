@@ -334,7 +334,8 @@ struct RunnerArgs {
 };
 
 // FAST: the networks on the bf16 matrix rate with split operands (mlp_actor_critic_fast; R.blob = host-packed image)
-template <int INTEG, int RMODE, bool FAST>
+// PARAMS: per-env mass / inertia (domain randomisation; RMODE 2 redraws them at every episode start)
+template <int INTEG, int RMODE, bool PARAMS, bool FAST>
 __global__ __launch_bounds__(kBlock, 1) void k_runner_rollout(StepArgs A, RunnerArgs R)
 {
     __shared__ __attribute__((aligned(16))) char lds_raw[FAST ? kAcFastLdsBytes : (int)(ac_lds_floats() * sizeof(float))];
@@ -378,6 +379,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_runner_rollout(StepArgs A, Runner
     if (active) load_env(A.st, tile, lane, e);
     else { nominal_init(e.sc, e.st); for (int i = 0; i < 4; ++i) { e.uc[i] = 0.0f; e.ut[i] = 0.0f; e.qd[i] = i == 0; } e.ls = 0.0f; e.t = 0.0f; }
     Par P = A.par_nom;
+    if (PARAMS && active) P = load_par(A.par, tile, lane);
     const uint64_t k0 = active ? step_counter_begin(A, tile) : 0;
     bool done_prev = (active && R.dones_in) ? R.dones_in[env] != 0 : false;
     float obs[12];
@@ -424,7 +426,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_runner_rollout(StepArgs A, Runner
         float reward;
         unsigned flags;
         bool done;
-        step_and_maybe_reset<INTEG, false, RMODE>(e, P, a, A, active ? env : 0, k0 + (uint64_t)t, obs, reward, flags, done, false);
+        step_and_maybe_reset<INTEG, PARAMS, RMODE>(e, P, a, A, active ? env : 0, k0 + (uint64_t)t, obs, reward, flags, done, false);
         done_prev = done;
         if (active) {
             A.reward[o] = reward;
@@ -440,6 +442,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_runner_rollout(StepArgs A, Runner
         R.last_dones[env] = done_prev ? 1 : 0;
         if (R.last_obs) store_obs(R.last_obs, env, obs);
         store_env(A.st, tile, lane, e);
+        if (PARAMS && RMODE == 2) store_par(A.par, tile, lane, P);
         step_counter_end(A, tile, lane, k0);
     }
 }
@@ -1567,8 +1570,8 @@ static int runner_launch(QsEnv *e, const char *who, int64_t T, const float logst
         return fail(QS_ERR_INVALID, "%s: bad arguments", who);
     if (e->cfg.io_space != QS_IO_DEVICE) return fail(QS_ERR_INVALID, "%s: device buffers only", who);
     if (!e->cfg.auto_reset) return fail(QS_ERR_INVALID, "%s: requires auto_reset", who);
-    if (e->cfg.kind == QS_KIND_HOVERING_V0 || e->per_env_params || e->init || e->cfg.randomise > 1)
-        return fail(QS_ERR_INVALID, "%s: docking-v0/v2 with nominal or rocRAND-initialised resets only", who);
+    if (e->cfg.kind == QS_KIND_HOVERING_V0 || e->init)
+        return fail(QS_ERR_INVALID, "%s: docking-v0/v2 with nominal or rocRAND resets only (no stored initial states)", who);
     StepArgs A = make_args(e);
     A.T = T; A.obs = mb_obs; A.reward = mb_rewards; A.done = mb_dones; A.flags = mb_flags;
     RunnerArgs R{};
@@ -1589,16 +1592,20 @@ static int runner_launch(QsEnv *e, const char *who, int64_t T, const float logst
     const unsigned grid = grid_tiles(e->n);
     const bool fr = e->cfg.integrator == QS_INTEG_FROZEN;
     const int rm = e->cfg.randomise;
-#define QS_RUNNER_LAUNCH(FAST)                                                                                          \
-    do {                                                                                                                \
-        if (fr && rm == 0) hipLaunchKernelGGL((k_runner_rollout<0, 0, FAST>), dim3(grid), dim3(kBlock), 0, e->stream, A, R); \
-        else if (fr) hipLaunchKernelGGL((k_runner_rollout<0, 1, FAST>), dim3(grid), dim3(kBlock), 0, e->stream, A, R);  \
-        else if (rm == 0) hipLaunchKernelGGL((k_runner_rollout<1, 0, FAST>), dim3(grid), dim3(kBlock), 0, e->stream, A, R); \
-        else hipLaunchKernelGGL((k_runner_rollout<1, 1, FAST>), dim3(grid), dim3(kBlock), 0, e->stream, A, R);          \
+    const bool params = e->per_env_params || rm == 2;
+#define QS_RUNNER_GO(I, RM, PA, FAST) hipLaunchKernelGGL((k_runner_rollout<I, RM, PA, FAST>), dim3(grid), dim3(kBlock), 0, e->stream, A, R)
+#define QS_RUNNER_INTEG(I, FAST)                                  \
+    do {                                                          \
+        if (rm == 2) QS_RUNNER_GO(I, 2, true, FAST);              \
+        else if (rm == 1 && params) QS_RUNNER_GO(I, 1, true, FAST);  \
+        else if (rm == 1) QS_RUNNER_GO(I, 1, false, FAST);        \
+        else if (params) QS_RUNNER_GO(I, 0, true, FAST);          \
+        else QS_RUNNER_GO(I, 0, false, FAST);                     \
     } while (0)
-    if (blob) QS_RUNNER_LAUNCH(true);
-    else QS_RUNNER_LAUNCH(false);
-#undef QS_RUNNER_LAUNCH
+    if (blob) { if (fr) QS_RUNNER_INTEG(0, true); else QS_RUNNER_INTEG(1, true); }
+    else { if (fr) QS_RUNNER_INTEG(0, false); else QS_RUNNER_INTEG(1, false); }
+#undef QS_RUNNER_INTEG
+#undef QS_RUNNER_GO
     HIP_TRY(hipGetLastError());
     return QS_OK;
 }

@@ -1173,3 +1173,38 @@ def test_baseline_config2_rk4_dt001_vs_oracle(qa):
             assert np.all(np.abs(rew[safe] - r[safe]) <= reward_atol(rec[safe, 38]) + reward_atol(r[safe]))
             np.testing.assert_allclose(state_to_rec(env.get_state())[safe][:, :38], rec[safe][:, :38], **STATE_TOL)
         env.close()
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_runner_rollout_domain_randomised(qa, precision):
+    """qs_runner_rollout(_fast) on envs with per-env mass / inertia redrawn at every episode start (randomise = 2, the
+    BASELINE config 5 setting): one step against the oracle's env.step with the per-env parameters, parameters redrawn
+    exactly where an episode ended"""
+    import torch
+    pol, W = _ac_policy(qa)
+    n, seed = 1500, 13
+    rr = tuple(qa.C3_INIT_RANGE) + (0.8, 1.2, 0.8, 1.2)
+    env = qa.VecDockingEnv("docking-v2", num_envs=n, randomise=2, seed=seed, init_range=rr[:4], mass_scale=rr[4:6],
+                           inertia_scale=rr[6:8])
+    env.reset()
+    tb = np.zeros(n, np.float32); tb[::3] = 599.0
+    env.set_state(t=tb)
+    m0, I0 = env.get_params()
+    assert m0.std() > 0.01
+    rec = state_to_rec(env.get_state()); par = np.concatenate([m0[:, None], I0], axis=1).astype(np.float64)
+    noise = torch.randn((1, n, 4), generator=torch.Generator().manual_seed(4))
+    k0 = env.step_counter
+    R = {k: v.cpu().numpy() for k, v in qa.fused_runner_rollout(env, pol, 1, noise=noise, precision=precision).items()
+         if v is not None}
+    a_env = np.clip(R["actions"][0], -1.0, 1.0)
+    orc = Oracle("f64")
+    o, r, d, f, term = orc.vec_step(rec, par, a_env, kind=1, randomise=2, seed=seed, step_idx=k0, rr=rr, want_term=True)
+    assert d[::3].all() and np.array_equal(R["last_dones"], d)
+    np.testing.assert_allclose(R["last_obs"], o, **OBS_TOL)
+    assert np.all(np.abs(R["rewards"][0] - r) <= reward_atol(rec[:, 38]) + reward_atol(r))
+    np.testing.assert_allclose(state_to_rec(env.get_state())[:, :38], rec[:, :38], **STATE_TOL)
+    m1, I1 = env.get_params()
+    np.testing.assert_allclose(m1, par[:, 0], rtol=1e-6); np.testing.assert_allclose(I1, par[:, 1:], rtol=1e-6)
+    moved = m1 != m0
+    assert np.array_equal(moved, d.astype(bool))                    # redrawn exactly where an episode ended
+    env.close()
