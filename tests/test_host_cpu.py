@@ -246,3 +246,26 @@ def test_runner_episode_bookkeeping_across_runs():
         np.testing.assert_allclose([e["r"] for e in got], [x for x, _ in want], atol=1e-4)
         np.testing.assert_allclose(r._ep_ret.numpy(), ep_ret, atol=1e-4)
         assert np.array_equal(r._ep_len.numpy(), ep_len)
+
+
+def test_packed_weight_images_match_the_library_layout():
+    """host-side packers of the split-bf16 weight images produce exactly the byte counts the kernels copy into LDS, and
+    hi + lo reproduces every weight to 2^-16 relative"""
+    import quadsim_amd as qa
+    from quadsim_amd import _lib
+    from quadsim_amd.policy import _bf16_to_f32, pack_fast_weights
+    from quadsim_amd.runner import pack_fast_actor_critic
+    lib = _lib.load()
+    path = os.path.join(ROOT, "tests", "golden", "policy_best_model_v0.npz")
+    ac = qa.ActorCriticPolicy.from_npz(path, device="cpu")
+    blob = pack_fast_actor_critic(ac)
+    assert blob.size == lib.qs_runner_rollout_fast_blob_bytes()
+    assert pack_fast_weights(qa.MlpPolicy.from_npz(path, device="cpu")).size == lib.qs_policy_rollout_fast_blob_bytes()
+    # A2 of the policy branch: fragment [nt][p][lane][j] holds W[16 nt + c][16 (2p + (j >> 2)) + 4 g + (j & 3)]
+    hi = _bf16_to_f32(blob[:32768].view(np.uint16)).reshape(8, 4, 64, 8)
+    lo = _bf16_to_f32(blob[32768:65536].view(np.uint16)).reshape(8, 4, 64, 8)
+    wt = ac.w1.numpy().T
+    for nt, p, lane, j in [(0, 0, 0, 0), (3, 2, 37, 5), (7, 3, 63, 7)]:
+        c, g = lane & 15, lane >> 4
+        w = wt[16 * nt + c, 16 * (2 * p + (j >> 2)) + 4 * g + (j & 3)]
+        assert abs((hi[nt, p, lane, j] + lo[nt, p, lane, j]) - w) <= abs(w) * 2.0 ** -16 + 1e-12
