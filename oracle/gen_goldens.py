@@ -19,6 +19,7 @@ Fixture sets:
   g6_sim_pid        run_sim_PID.py:8-54 hover loop, 2000 steps (BASELINE config 1)
   g7_domain_rand    v0/v2 trajectories with patched mass / inertia
   g8_traj_v1        docking-v1 (construction-time chaser jitter) trajectories, three constructions
+  g12_dock_port     Drone.get_dock_port_state for random states / ports
   g11_expert_episode PID expert (vel_controller on the chaser + inverse action map) on docking-v0
   g10_gae           GAE(lambda) + swap_and_flatten of the in-tree PPO2 Runner (reference lines executed)
   g9_hovering       hovering-v0 trajectories (raw-state obs, own reward/done), three constructions
@@ -183,6 +184,26 @@ def gen_g2(n=400, seed=202):
     sat = int(np.sum(np.abs(Rm[:, 1, 2]) >= 1)), int(np.sum(np.abs(2 * (q[:, 0] * q[:, 1] + q[:, 2] * q[:, 3])) >= 1))
     print("g2: saturated rot2euler cases %d, quat2euler cases %d" % sat)
     save("g2_transforms", quat=q, quat2euler=q2e, euler=e_in, euler2quat=e2q, quat2rot=q2r, rot=Rm, rot2euler=r2e)
+
+
+def gen_g12(n=300, seed=1212):
+    """Drone.get_dock_port_state (dynamics/quadrotor.py:213-224) for random states and the three ports in use"""
+    rs = np.random.RandomState(seed)
+    S = np.zeros((n, 13))
+    S[:, 0:3] = rs.normal(0, 20, (n, 3)); S[:, 3:6] = rs.normal(0, 2, (n, 3))
+    q = rs.normal(0, 1, (n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q[n // 2:] *= rs.uniform(0.7, 1.4, (n - n // 2, 1))
+    S[:, 6:10] = q; S[:, 10:13] = rs.normal(0, 2, (n, 3))
+    ports = np.array([[0.1, 0, 0], [-0.1, 0, 0], [0.05, 0, 0]])
+    P = ports[rs.randint(0, 3, n)]
+    pos, vel, quat, rate = [], [], [], []
+    d = quadrotor.Drone()
+    for i in range(n):
+        d.reset(reset_state=S[i].copy(), dock_port=P[i].copy())
+        dp = d.get_dock_port_state()
+        pos.append(dp["pos"]); vel.append(dp["vel"]); quat.append(dp["quat"]); rate.append(dp["angular_rate"])
+    save("g12_dock_port", state=S, port=P, pos=np.array(pos), vel=np.array(vel), quat=np.array(quat, np.float64),
+         angular_rate=np.array(rate))
 
 
 def gen_g3(n=400, seed=303):
@@ -499,6 +520,6 @@ def gen_g10():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     for w in which:
         globals()["gen_" + w]()

@@ -148,6 +148,18 @@ class Drone:
     def get_mass(self):
         return self.mass
 
+    def get_dock_port_state(self):
+        """dynamics/quadrotor.py:213-224: {'pos', 'vel', 'quat', 'angular_rate'} of the dock port.  quat2rot runs on the
+        GPU (qs_transform); the two 3-vector products are layer-1 glue, not the env path (the fused step evaluates the
+        ports in-kernel and never needs 'quat', which state2rel ignores, docking_env.py:263-264).  With the reference's
+        unit-diagonal "rotation" the trace branch of rot2quat (:259-289) always fires: quat = (1, q0 n1, q0 n2, q0 n3)."""
+        R = transform_batch("quat2rot", self.state[6:10][None], device=self._device)[0].astype(np.float64)
+        b = R.T @ self.dock_port_inB_pos
+        w = self.state[10:13]
+        quat = np.array([1.0, (R[2, 1] - R[1, 2]) / 4.0, (R[0, 2] - R[2, 0]) / 4.0, (R[1, 0] - R[0, 1]) / 4.0], np.float32)
+        return {"pos": self.state[0:3] + b, "vel": self.state[3:6] + np.cross(w, b), "quat": quat,
+                "angular_rate": self.state[10:].copy()}
+
 
 class controller:
     """controller/PIDController.py:7-50 surface; PID / vel_controller mutate state_des[6:12] in place."""

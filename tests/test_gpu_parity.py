@@ -1208,3 +1208,17 @@ def test_runner_rollout_domain_randomised(qa, precision):
     moved = m1 != m0
     assert np.array_equal(moved, d.astype(bool))                    # redrawn exactly where an episode ended
     env.close()
+
+
+def test_g12_drone_dock_port_state(qa):
+    """Drone.get_dock_port_state of the layer-1 mirror against the reference's own outputs (fixture g12), including the
+    quirk that its 'quat' is always (1, q0 n1, q0 n2, q0 n3): the trace branch of rot2quat on a unit-diagonal matrix"""
+    g = load_golden("g12_dock_port")
+    d = qa.Drone()
+    for i in range(0, g["state"].shape[0], 3):
+        d.reset(reset_state=g["state"][i], dock_port=g["port"][i])
+        dp = d.get_dock_port_state()
+        np.testing.assert_allclose(dp["pos"], g["pos"][i], rtol=1e-6, atol=1e-5)
+        np.testing.assert_allclose(dp["vel"], g["vel"][i], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(dp["quat"], g["quat"][i], rtol=1e-5, atol=1e-6)
+        np.testing.assert_array_equal(dp["angular_rate"], g["angular_rate"][i])

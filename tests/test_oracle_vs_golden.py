@@ -269,3 +269,12 @@ def test_g11_expert_episode(oracle64):
         assert abs(rew - g["rewards"][t]) < 1e-8 and done == bool(g["done"][t])
         ret += rew
     assert abs(ret - 0.8418) < 1e-3 and done
+
+
+def test_g12_dock_port_state(oracle64):
+    """Drone.get_dock_port_state (quadrotor.py:213-224): position / velocity of the port for the three ports in use"""
+    g = load_golden("g12_dock_port")
+    for i in range(g["state"].shape[0]):
+        pos, vel = oracle64.dock_port(g["state"][i], g["port"][i])
+        np.testing.assert_allclose(pos, g["pos"][i], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(vel, g["vel"][i], rtol=0, atol=1e-12)
