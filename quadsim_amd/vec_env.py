@@ -259,6 +259,20 @@ class VecDockingEnv:
     def render(self, mode="human"):
         return None
 
+    # what stable_baselines' VecEnvWrapper machinery (VecNormalize, VecCheckNan, ...) asks of the wrapped VecEnv
+    @property
+    def unwrapped(self):
+        return self
+
+    def get_images(self):
+        return []
+
+    def getattr_depth_check(self, name, already_found):
+        return None
+
+    def _get_target_envs(self, indices):
+        return [self for _ in (range(self.num_envs) if indices is None else indices)]
+
     def get_attr(self, name, indices=None):
         idx = range(self.num_envs) if indices is None else indices
         if name in ("state_chaser", "state_target"):
