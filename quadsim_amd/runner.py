@@ -182,12 +182,16 @@ class Runner:
     prefer ``collect_ep_infos=False`` and read the device tensors ``last_ep_returns`` / ``last_ep_lengths``."""
 
     def __init__(self, *, env, model, n_steps, gamma, lam, reset_after_run=False, collect_ep_infos=True,
-                 track_episodes=True, precision="f32"):
+                 track_episodes=True, precision="f32", fused=None):
         import torch
         self.torch = torch
         self.env, self.model, self.n_steps, self.gamma, self.lam = env, model, int(n_steps), float(gamma), float(lam)
         self.reset_after_run = reset_after_run
         self.precision = precision                     # "f32" | "bf16x3" (fused_runner_rollout)
+        # fused: the whole n_steps loop in one launch (docking envs + the shipped MlpPolicy architecture); None = whenever
+        # it applies, else the spelt-out loop (model.step on torch + env.step)
+        can_fuse = isinstance(model, ActorCriticPolicy) and env.obs_dim == 12 and getattr(env, "auto_reset", True)
+        self.fused = can_fuse if fused is None else bool(fused)
         self.collect_ep_infos = collect_ep_infos       # build the reference's list of {'r', 'l'} dicts on the host
         self.track_episodes = track_episodes           # keep episode returns / lengths at all (device tensors
         self.last_ep_returns = self.last_ep_lengths = None   # last_ep_returns / last_ep_lengths after each run)
@@ -221,11 +225,35 @@ class Runner:
         l_ = self.last_ep_lengths.cpu().numpy()
         return [{"r": float(a), "l": int(b)} for a, b in zip(r, l_)]
 
+    def _stepwise_rollout(self, noise=None):
+        """the reference loop spelt out (ppo2.py:472-499): model.step on torch, env.step per step.  For envs / policies the
+        fused kernel does not cover (hovering-v0, stored initial states, any other network): still no host round trip."""
+        t = self.torch
+        env, T = self.env, self.n_steps
+        obs = self.obs if self.obs is not None else env.reset()
+        dones = self.dones.bool()
+        lo = t.as_tensor(env.action_space.low, device=env.device); hi = t.as_tensor(env.action_space.high, device=env.device)
+        O, A, V, NL, D, R = [], [], [], [], [], []
+        for k in range(T):
+            kw = {} if noise is None else {"noise": noise[k]}
+            u, v, self.states, nl = self.model.step(obs, self.states, dones, **kw)
+            O.append(obs.clone()); A.append(u); V.append(v); NL.append(nl); D.append(dones.to(t.uint8))
+            a_env = self.model.env_action(u) if hasattr(self.model, "env_action") else t.max(t.min(u, hi), lo)   # :483
+            obs, r, dones, _ = env.step(a_env)
+            obs, dones = obs.clone(), dones.clone()
+            R.append(r.clone())
+        return {"obs": t.stack(O), "actions": t.stack(A), "values": t.stack(V), "neglogp": t.stack(NL), "dones": t.stack(D),
+                "rewards": t.stack(R), "last_obs": obs, "last_values": self.model.value(obs, self.states, dones),
+                "last_dones": dones.to(t.uint8)}
+
     def run(self, noise=None):
         t = self.torch
         env, T = self.env, self.n_steps
         mb_states = self.states
-        ro = fused_runner_rollout(env, self.model, T, noise=noise, dones_in=self.dones, precision=self.precision)
+        if self.fused:
+            ro = fused_runner_rollout(env, self.model, T, noise=noise, dones_in=self.dones, precision=self.precision)
+        else:
+            ro = self._stepwise_rollout(noise)
         self.num_timesteps += T * env.num_envs
         mb_advs, mb_returns = compute_gae(env, ro["rewards"], ro["values"], ro["dones"], ro["last_values"],
                                           ro["last_dones"], self.gamma, self.lam)          # ppo2.py:507-520

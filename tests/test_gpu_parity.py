@@ -1222,3 +1222,50 @@ def test_g12_drone_dock_port_state(qa):
         np.testing.assert_allclose(dp["vel"], g["vel"][i], rtol=1e-5, atol=1e-5)
         np.testing.assert_allclose(dp["quat"], g["quat"][i], rtol=1e-5, atol=1e-6)
         np.testing.assert_array_equal(dp["angular_rate"], g["angular_rate"][i])
+
+
+def test_runner_stepwise_path_and_hovering(qa, oracle64):
+    """Runner(fused=False): the reference loop spelt out (torch model.step + env.step) returns what the fused launch
+    returns for the same noise; and it serves what the fused kernel does not cover -- hovering-v0 with an arbitrary
+    policy object (13-d observations, actions in [0,1]^4)"""
+    import torch
+    pol, _ = _ac_policy(qa)
+    n, T = 400, 30
+    kw = dict(num_envs=n, randomise=1, seed=8, init_range=qa.C3_INIT_RANGE)
+    e1 = qa.VecDockingEnv("docking-v0", **kw); e2 = qa.VecDockingEnv("docking-v0", **kw)
+    r1 = qa.Runner(env=e1, model=pol, n_steps=T, gamma=0.99, lam=0.95)
+    r2 = qa.Runner(env=e2, model=pol, n_steps=T, gamma=0.99, lam=0.95, fused=False)
+    assert r1.fused and not r2.fused
+    noise = torch.randn((T, n, 4), generator=torch.Generator().manual_seed(6)).to(e1.device)
+    a = r1.run(noise=noise); b = r2.run(noise=noise)
+    for i in (0, 1, 3, 4, 5, 8):                                    # obs, returns, actions, values, neglogp, true_reward
+        np.testing.assert_allclose(b[i].cpu().numpy(), a[i].cpu().numpy(), rtol=2e-3, atol=2e-2 if i == 5 else 5e-3)
+    assert np.array_equal(a[2].cpu().numpy(), b[2].cpu().numpy()) and len(a[7]) == len(b[7])
+    e1.close(); e2.close()
+
+    class RandomHoverPolicy:                                         # any object with step / value works stepwise
+        initial_state = None
+
+        def __init__(self, dev):
+            g = torch.Generator().manual_seed(0)
+            self.w = (torch.randn((13, 4), generator=g) * 0.01).to(dev); self.v = (torch.randn((13,), generator=g) * 0.1).to(dev)
+
+        def step(self, obs, state=None, mask=None):
+            mean = 0.5 + obs @ self.w
+            u = mean + 0.05 * torch.randn_like(mean)
+            return u, obs @ self.v, None, ((u - mean) ** 2).sum(-1)
+
+        def value(self, obs, state=None, mask=None):
+            return obs @ self.v
+
+    hov = qa.VecDockingEnv("hovering-v0", num_envs=256, seed=1)
+    rh = qa.Runner(env=hov, model=RandomHoverPolicy(hov.device), n_steps=20, gamma=0.99, lam=0.95)
+    assert not rh.fused
+    obs, returns, masks, actions, values, neglogp, states, ep_infos, true_reward = rh.run()
+    assert obs.shape == (256 * 20, 13) and actions.shape == (256 * 20, 4) and returns.shape == (256 * 20,)
+    f = lambda x: x.cpu().numpy().reshape(256, 20).T                              # noqa: E731
+    adv, ret = oracle64.gae(f(true_reward), f(values), f(masks).astype(np.uint8), rh.model.value(rh.obs).cpu().numpy(),
+                            rh.dones.cpu().numpy(), 0.99, 0.95)
+    np.testing.assert_allclose(f(returns), ret, rtol=1e-4, atol=1e-4)
+    assert float(actions.min()) < 0.5 < float(actions.max())
+    hov.close()
