@@ -1269,3 +1269,23 @@ def test_runner_stepwise_path_and_hovering(qa, oracle64):
     np.testing.assert_allclose(f(returns), ret, rtol=1e-4, atol=1e-4)
     assert float(actions.min()) < 0.5 < float(actions.max())
     hov.close()
+
+
+def test_c_abi_from_plain_c(qa, tmp_path):
+    """include/quadsim.h is plain C: examples/c_api_demo.c builds with gcc -std=c99 against the library and reproduces the
+    reference's known answers (reset obs 1.8, first reward -6.1 for the hover action, vz = -0.1962 after one step) in a
+    process that never loads Python or torch"""
+    import os, subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "c_api_demo")
+    libdir = os.path.join(root, "quadsim_amd", "csrc")
+    subprocess.check_call(["gcc", "-std=c99", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "examples", "c_api_demo.c"), "-L" + libdir, "-lquadsim_hip", "-L/opt/rocm/lib",
+                           "-lamdhip64", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    vals = dict(line.split(" = ") for line in out.stdout.strip().splitlines())
+    assert abs(float(vals["reset obs[0]"]) - 1.8) < 1e-6
+    assert abs(float(vals["first reward"]) + 6.1) < 1e-5
+    assert abs(float(vals["chaser vz after step 1"]) + 0.1962) < 1e-6
+    assert int(vals["steps"]) == 201
