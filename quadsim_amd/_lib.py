@@ -67,9 +67,12 @@ def build_library(force=False, verbose=False):
     if (not force and os.path.exists(LIB_PATH)
             and all(os.path.getmtime(LIB_PATH) >= os.path.getmtime(d) for d in deps)):
         return LIB_PATH
+    # -ffp-contract=on: a*b+c fuses only where one expression says so, so every kernel that inlines the same device
+    # function computes the same bits (the serial and the role-split step kernel, the policy kernels' env step);
+    # hipcc's default (fast) fuses across statements depending on the surrounding code.  Same instruction count.
     # -fno-slp-vectorize: SLP packs the scalar f32 chains into v_pk_* pairs at the price of ~300 extra
     # v_mov and +56 VGPRs; measured 5 % slower on the step kernel (profiles/r01/ab_slp.txt)
-    cmd = [hipcc_path(), "-std=c++20", "-O3", "-fno-slp-vectorize", "--offload-arch=gfx950", "-fPIC", "-shared",
+    cmd = [hipcc_path(), "-std=c++20", "-O3", "-fno-slp-vectorize", "-ffp-contract=on", "--offload-arch=gfx950", "-fPIC", "-shared",
            "-Wno-unused-result", *SOURCES, "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))

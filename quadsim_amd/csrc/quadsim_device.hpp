@@ -293,8 +293,9 @@ __device__ __forceinline__ void u_limit(const float u[4], float mg, float out[4]
 
 // Drone.step, dynamics/quadrotor.py:126-144: integrate with the PREVIOUS limited
 // control, clamp attitude, then store the newly limited control.
+// integration + attitude clamp with the PREVIOUS limited control (everything of Drone.step but the control hand-over)
 template <int INTEG>
-__device__ __forceinline__ bool drone_step(float s[13], float u_prev[4], const float u[4], const Par &P, float dt)
+__device__ __forceinline__ bool drone_advance(float s[13], const float u_prev[4], const Par &P, float dt)
 {
     float inv_m = q_rcp(P.m);
     float k1[13];
@@ -319,7 +320,13 @@ __device__ __forceinline__ bool drone_step(float s[13], float u_prev[4], const f
 #pragma unroll
         for (int i = 0; i < 13; ++i) s[i] = fmaf(d6, (k1[i] + k4[i]) + 2.0f * (k2[i] + k3[i]), s[i]);
     }
-    bool over = attitude_limit(s);
+    return attitude_limit(s);
+}
+
+template <int INTEG>
+__device__ __forceinline__ bool drone_step(float s[13], float u_prev[4], const float u[4], const Par &P, float dt)
+{
+    bool over = drone_advance<INTEG>(s, u_prev, P, dt);
     u_limit(u, P.m * kG, u_prev);
     return over;
 }
@@ -470,12 +477,17 @@ __device__ __forceinline__ uint4 philox_block(uint64_t seed, uint64_t stream, ui
 // u[2j] = low half, u[2j+1] = high half of word j.  Half-angles stay below pi/4 (qs_create checks
 // init_range[2] <= pi/2), so the reduction-free sincos applies.
 // Build extension; the reference's v0/v2 have no randomness.
-template <bool WITH_PAR>
-__device__ __forceinline__ void random_init(const RandCfg &rc, uint64_t stream, uint64_t gid, uint64_t ctr,
-                                            float sc[13], float st[13], Par &P)
+__device__ __forceinline__ void random_init_words(const RandCfg &rc, uint64_t stream, uint64_t gid, uint64_t ctr,
+                                                  uint4 &w0, uint4 &w1)
 {
-    uint4 w0 = philox_block(rc.seed, stream, gid, 2ull * ctr + 0);
-    uint4 w1 = philox_block(rc.seed, stream, gid, 2ull * ctr + 1);
+    w0 = philox_block(rc.seed, stream, gid, 2ull * ctr + 0);
+    w1 = philox_block(rc.seed, stream, gid, 2ull * ctr + 1);
+}
+
+template <bool WITH_PAR>
+__device__ __forceinline__ void random_init_apply(const RandCfg &rc, const uint4 &w0, const uint4 &w1, float sc[13],
+                                                  float st[13], Par &P)
+{
     nominal_init(sc, st);
     sc[0] = __fmaf_rn(sym(u16lo(w0.x)), rc.rr[0], 8.0f);
     sc[1] = __fmaf_rn(sym(u16hi(w0.x)), rc.rr[0], -50.0f);
@@ -502,6 +514,15 @@ __device__ __forceinline__ void random_init(const RandCfg &rc, uint64_t stream, 
     } else {
         P = Par{rc.par_nom[0], rc.par_nom[1], rc.par_nom[2], rc.par_nom[3]};
     }
+}
+
+template <bool WITH_PAR>
+__device__ __forceinline__ void random_init(const RandCfg &rc, uint64_t stream, uint64_t gid, uint64_t ctr,
+                                            float sc[13], float st[13], Par &P)
+{
+    uint4 w0, w1;
+    random_init_words(rc, stream, gid, ctr, w0, w1);
+    random_init_apply<WITH_PAR>(rc, w0, w1, sc, st, P);
 }
 
 __device__ __forceinline__ void random_action(uint64_t seed, uint64_t gid, uint64_t k, float a[4])

@@ -15,6 +15,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -31,6 +32,10 @@ namespace {
 #define QS_BLOCK 256
 #endif
 constexpr int kBlock = QS_BLOCK;  // 4 wavefronts = 4 tiles per workgroup
+#ifndef QS_SPLIT_MAX_ENVS
+#define QS_SPLIT_MAX_ENVS 131072
+#endif
+constexpr int64_t kSplitMaxEnvs = QS_SPLIT_MAX_ENVS;
 
 struct StepArgs {
     float *st;             // [tiles][40][64]
@@ -211,6 +216,180 @@ __global__ __launch_bounds__(kBlock) void k_env(StepArgs A)
     store_env(A.st, tile, lane, e);
     if (PARAMS && RMODE == 2) store_par(A.par, tile, lane, P);
     step_counter_end(A, tile, lane, k0);
+}
+
+// Role-split variant of k_env: one workgroup = one tile = TWO waves.  Wave 0 carries the chaser side of the 64 envs (action
+// mix, chaser drone step, state2rel, reward, done, the chaser's reset), wave 1 the target side (target drone step, the
+// target's PID, the rocRAND draw a reset of this step would consume).  A lone wave issues a vector instruction every 4
+// cycles and two waves on a SIMD every 2 each (MI355X_MICROARCH.md), so at one tile per SIMD the two half-length
+// instruction streams run in the time of one.  Hand-overs through 7.5 KiB of LDS, two workgroup barriers per step:
+//   target wave:  advance target | draw Philox words  -> #1 ->  PID, limit new control            -> #2 -> apply reset
+//   chaser wave:  mix, advance chaser                 -> #1 ->  state2rel, reward, done -> flag  -> #2 -> reset, stores
+template <int INTEG, bool PARAMS, int RMODE>
+__global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
+{
+    __shared__ float s_tgt[13][kTile];
+    __shared__ uint4 s_phx[2][2][kTile];          // [step parity][block]: the chaser wave reads step t's words while t+1's are drawn
+    __shared__ unsigned char s_done[kTile], s_limt[kTile];
+    const int lane = threadIdx.x & (kTile - 1);
+    const int role = threadIdx.x >> 6;
+    const int64_t tile = blockIdx.x;
+    const int64_t env = tile * kTile + lane;
+    const bool active = env < A.n;               // idle lanes of the tail tile compute on zeros and store nothing
+    const uint64_t k0 = step_counter_begin(A, tile);
+    const float *b = A.st + tile * (int64_t)(kRecWords * kTile) + lane;
+    float *bw = A.st + tile * (int64_t)(kRecWords * kTile) + lane;
+    Par P = A.par_nom;
+    if (PARAMS) P = load_par(A.par, tile, lane);
+    if (role == 0) {
+        float4 av_next = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (A.actions && active) av_next = reinterpret_cast<const float4 *>(A.actions)[env];
+        float sc[13], uc[4];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) sc[i] = b[(F_SC + i) * kTile];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) uc[i] = b[(F_UC + i) * kTile];
+        float ls = b[F_LS * kTile], tt = b[F_T * kTile];
+#pragma clang loop unroll(disable)
+        for (int64_t t = 0; t < A.T; ++t) {
+            const uint64_t k = k0 + (uint64_t)t;
+            const int64_t o = t * A.n + env;
+            float a[4];
+            if (A.actions) {
+                const float4 av = av_next;
+                if (t + 1 < A.T && active) av_next = reinterpret_cast<const float4 *>(A.actions)[o + A.n];
+                a[0] = av.x; a[1] = av.y; a[2] = av.z; a[3] = av.w;
+            } else {
+                random_action(A.rc.seed, A.gid0 + (uint64_t)env, k, a);
+            }
+            tt += 1.0f;
+            float u_c[4];
+            chaser_command(a, P.m, u_c);
+            const bool lim_c = drone_step<INTEG>(sc, uc, u_c, P, A.C.dt);
+            __syncthreads();                                              // #1: the target's new state is in LDS
+            float st[13];
+#pragma unroll
+            for (int i = 0; i < 13; ++i) st[i] = s_tgt[i][lane];
+            const bool lim_t = s_limt[lane] != 0;
+            float obs[12], reward;
+            unsigned flags;
+            rel_obs(sc, st, obs);
+            score_step(obs, a, sc[2], tt, ls, A.C, lim_c, lim_t, reward, flags);
+            const bool done = (flags & (FLAG_OVERLIMIT | FLAG_OVERTIME)) != 0;
+            const bool rs = done && A.auto_reset;
+            s_done[lane] = rs ? 1 : 0;
+            __syncthreads();                                              // #2: reset flags out, this step's Philox words in
+            if (rs) {
+                if (A.term_obs && active) store_obs(A.term_obs, env, obs);
+                float ic[13], it[13];
+                if (RMODE == 0) {
+                    nominal_init(ic, it);
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) obs[i] = A.nominal_obs[i];
+                } else if (RMODE == 3) {
+                    const float *src = A.init + (active ? env : 0) * 26;
+#pragma unroll
+                    for (int i = 0; i < 13; ++i) { ic[i] = src[i]; it[i] = src[13 + i]; }
+                    rel_obs<false>(ic, it, obs);
+                } else {
+                    const uint4 w0 = s_phx[t & 1][0][lane], w1 = s_phx[t & 1][1][lane];
+                    Par Pn;
+                    random_init_apply<RMODE == 2>(A.rc, w0, w1, ic, it, Pn);
+                    if (PARAMS && RMODE == 2) P = Pn;
+                    rel_obs<true>(ic, it, obs);
+                }
+#pragma unroll
+                for (int i = 0; i < 13; ++i) sc[i] = ic[i];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) uc[i] = 0.0f;
+                ls = 0.0f;
+                tt = 0.0f;
+            }
+            if (active) {
+                if (A.slab) {
+                    float2 *row = reinterpret_cast<float2 *>(A.slab + o * 14);
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) row[i] = make_float2(obs[2 * i], obs[2 * i + 1]);
+                    row[6] = make_float2(reward, done ? 1.0f : 0.0f);
+                } else {
+                    store_obs(A.obs, o, obs);
+                    A.reward[o] = reward;
+                    A.done[o] = done ? 1 : 0;
+                }
+                if (A.flags) A.flags[o] = (uint8_t)flags;
+            }
+        }
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < 13; ++i) bw[(F_SC + i) * kTile] = sc[i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bw[(F_UC + i) * kTile] = uc[i];
+            bw[F_LS * kTile] = ls;
+            bw[F_T * kTile] = tt;
+            if (PARAMS && RMODE == 2) store_par(A.par, tile, lane, P);
+        }
+        step_counter_end(A, tile, lane, k0);
+    } else {
+        float st[13], ut[4], qd[4];
+#pragma unroll
+        for (int i = 0; i < 13; ++i) st[i] = b[(F_ST + i) * kTile];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) ut[i] = b[(F_UT + i) * kTile];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) qd[i] = b[(F_QD + i) * kTile];
+        const float pdes[3] = {10.0f, -50.0f, 5.0f};              // docking_env.py:60
+        const float vdes[3] = {A.C.vdes_x, 0.0f, 0.0f};
+        const float dv[3] = {0.0f, 0.0f, 0.0f};
+#pragma clang loop unroll(disable)
+        for (int64_t t = 0; t < A.T; ++t) {
+            const uint64_t k = k0 + (uint64_t)t;
+            float pre[13];
+#pragma unroll
+            for (int i = 0; i < 13; ++i) pre[i] = st[i];
+            const bool lim_t = drone_advance<INTEG>(st, ut, P, A.C.dt);   // with the previous limited control
+#pragma unroll
+            for (int i = 0; i < 13; ++i) s_tgt[i][lane] = st[i];
+            s_limt[lane] = lim_t ? 1 : 0;
+            uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0;
+            if (RMODE == 1 || RMODE == 2) {
+                random_init_words(A.rc, STREAM_AUTORESET, A.gid0 + (uint64_t)env, k + 1, w0, w1);
+                s_phx[t & 1][0][lane] = w0;
+                s_phx[t & 1][1][lane] = w1;
+            }
+            __syncthreads();                                              // #1
+            float u_t[4];
+            target_control(A.C.kind, pdes, vdes, qd, 0.0f, pre, dv, P.m, u_t);   // from the state BEFORE stepping
+            u_limit(u_t, P.m * kG, ut);
+            __syncthreads();                                              // #2
+            if (s_done[lane]) {
+                float ic[13], it[13];
+                if (RMODE == 3) {
+                    const float *src = A.init + (active ? env : 0) * 26;
+#pragma unroll
+                    for (int i = 0; i < 13; ++i) it[i] = src[13 + i];
+                } else {
+                    nominal_init(ic, it);
+                    if (PARAMS && RMODE == 2) {
+                        Par Pn;
+                        random_init_apply<true>(A.rc, w0, w1, ic, it, Pn);
+                        P = Pn;
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 13; ++i) st[i] = it[i];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ut[i] = 0.0f;
+            }
+        }
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < 13; ++i) bw[(F_ST + i) * kTile] = st[i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bw[(F_UT + i) * kTile] = ut[i];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) bw[(F_QD + i) * kTile] = qd[i];
+        }
+    }
 }
 
 // Policy-in-the-loop roll-out: T steps of  a = clip(MLP(obs));  obs, r, done = env.step(a)  in one launch
@@ -919,7 +1098,13 @@ struct Bounce {
 template <int INTEG, bool PARAMS, int RMODE>
 void launch_one(unsigned grid, hipStream_t s, const StepArgs &A)
 {
-    hipLaunchKernelGGL((k_env<INTEG, PARAMS, RMODE>), dim3(grid), dim3(kBlock), 0, s, A);
+    // role-split kernel up to kSplitMaxEnvs envs (few waves per SIMD: the two half-length streams of a tile overlap), the
+    // serial kernel above (SIMDs already saturated: the hand-overs only cost).  Both inline the same device functions and
+    // the library is built with -ffp-contract=on, so they compute the same bits.  QS_SPLIT=0/1 forces one (A/B runs).
+    static const int forced = getenv("QS_SPLIT") ? atoi(getenv("QS_SPLIT")) : -1;
+    const bool split = forced >= 0 ? forced != 0 : A.n <= kSplitMaxEnvs;
+    if (split) hipLaunchKernelGGL((k_env_split<INTEG, PARAMS, RMODE>), dim3((unsigned)tiles_of(A.n)), dim3(2 * kTile), 0, s, A);
+    else hipLaunchKernelGGL((k_env<INTEG, PARAMS, RMODE>), dim3(grid), dim3(kBlock), 0, s, A);
 }
 
 template <int INTEG>
