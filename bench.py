@@ -192,7 +192,8 @@ def main():
                    "parallelism": "env-sharded x%d, no data-path collective" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": "k_env<%s> (T=1)" % args.integrator, "bytes_per_env_step": bpe,
+                     "kernel": ("k_env_split<%s> (T=1): two waves per tile" if n <= 131072 else "k_env<%s> (T=1)") % args.integrator,
+                     "bytes_per_env_step": bpe,
                      "bytes_per_launch": bpe * n, "launch_period_us": launch_us,
                      "read_frac": (176 if bpe == 392 else 192) * n / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                      "basis": "HIP events on the launching stream around the K timed launches / K "
