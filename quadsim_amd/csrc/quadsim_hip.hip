@@ -242,6 +242,9 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
     Par P = A.par_nom;
     if (PARAMS) P = load_par(A.par, tile, lane);
     if (role == 0) {
+        // in a roll-out the chaser wave is the long pole of every step while target waves on the same SIMD run ahead with
+        // speculative draws: give it the issue slots first (roll-out 2.28 -> 2.13 us/step; no help for a single step)
+        if (A.T > 1) __builtin_amdgcn_s_setprio(3);
         float4 av_next = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (A.actions && active) av_next = reinterpret_cast<const float4 *>(A.actions)[env];
         float sc[13], uc[4];
@@ -267,6 +270,7 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
             chaser_command(a, P.m, u_c);
             const bool lim_c = drone_step<INTEG>(sc, uc, u_c, P, A.C.dt);
             __syncthreads();                                              // #1: the target's new state is in LDS
+            if (A.T == 1) __builtin_amdgcn_s_setprio(3);                 // single step: from here on this wave is the long pole
             float st[13];
 #pragma unroll
             for (int i = 0; i < 13; ++i) st[i] = s_tgt[i][lane];
@@ -340,6 +344,7 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
         const float pdes[3] = {10.0f, -50.0f, 5.0f};              // docking_env.py:60
         const float vdes[3] = {A.C.vdes_x, 0.0f, 0.0f};
         const float dv[3] = {0.0f, 0.0f, 0.0f};
+        if (A.T == 1) __builtin_amdgcn_s_setprio(3);   // single step: the chaser wave waits at #1 for this wave's step + draw
 #pragma clang loop unroll(disable)
         for (int64_t t = 0; t < A.T; ++t) {
             const uint64_t k = k0 + (uint64_t)t;
@@ -357,6 +362,7 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
                 s_phx[t & 1][1][lane] = w1;
             }
             __syncthreads();                                              // #1
+            if (A.T == 1) __builtin_amdgcn_s_setprio(0);
             float u_t[4];
             target_control(A.C.kind, pdes, vdes, qd, 0.0f, pre, dv, P.m, u_t);   // from the state BEFORE stepping
             u_limit(u_t, P.m * kG, ut);
