@@ -2,23 +2,30 @@
 """bench.py -- env-steps/s of the fused docking env.step() hot path on MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    (N > 1: run as is -- the parent spawns one child per GPU before it touches the GPU -- or under
+     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one pass of the hot path over the batch: ONE qs_step launch stepping
-every env of this GPU once (BASELINE.json config 3: 65 536 docking-v0 envs per
-GPU, U(-1,1) random actions already resident in HBM, rocRAND randomised
-auto-reset).  Envs shard over GPUs by env id with no data-path collective
-(scaling "weak": 65 536 envs per GPU); the RCCL all-gather of roll-out slabs that
-BASELINE configs 4/5 mention is timed separately and reported under "allgather",
-never mixed into `value`.
+A "step" is one pass of the hot path over the batch: every env of this GPU stepped once through the step API
+(BASELINE.json config 3: 65 536 docking-v0 envs per GPU, U(-1,1) random actions already resident in HBM, rocRAND
+randomised auto-reset; state round-trips through HBM every step).  Envs shard over GPUs by env id with no data-path
+collective (scaling "weak": 65 536 envs per GPU); the RCCL all-gather of roll-out slabs that BASELINE configs 4/5
+mention is timed separately and reported under "allgather", never mixed into `value`.
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline" (HBM, algorithmic
-bytes / launch), "cpu_baseline" (the C oracle timed on the host cores),
-"rollout_fused" (qs_rollout: T steps per launch, state in registers).
+ONE clock: `value`, `ms_per_step` and `roofline.achieved / frac / read_frac` all come from the same host wall-clock
+interval (barrier + synchronize on both sides, max over ranks).  The interval holds R back-to-back blocks of EXACTLY K
+steps (R chosen so that R*K >= --min-timed-steps): a 20-step interval is shorter than the synchronisation that closes it
+(~30 us), so the per-step time is only meaningful over a few thousand steps.  The HIP-event time of the same launches is
+reported separately as `roofline.gpu_timeline_*`, and the rocprofv3 kernel average from the committed profile as
+`roofline.rocprof_*`.
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline", "parity" (fixture g4 = outputs of the NumPy reference
+replayed through qs_step), "cpu_baseline" (the C oracle on the host cores), "config1" (BASELINE config 1 on the CPU
+oracle), "rollout_fused", ...
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -28,6 +35,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec peak
 BYTES_PER_ENV_STEP = 392       # read 176 B + write 216 B per env-step (step-API mode)
 BYTES_PER_ENV_STEP_DR = 408    # + mass, Ixx, Iyy, Izz read (per-env params)
+READ_TARGET = 0.40             # north_star / SURVEY.md 8(d): >= 40 % of the HBM-read roofline <=> 18.2 G env-steps/s
+PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
 
 
 def parse():
@@ -40,17 +49,71 @@ def parse():
     p.add_argument("--integrator", default="frozen", choices=["frozen", "rk4"])
     p.add_argument("--randomise", type=int, default=1, help="0 nominal resets, 1 rocRAND init state, 2 + mass/inertia")
     p.add_argument("--action-pool", type=int, default=512, help="distinct pre-generated [N,4] action batches cycled")
+    p.add_argument("--groups", type=int, default=-1,
+                   help="env groups in flight (qs_set_groups): 1 = one launch per step; G > 1 = G chains on G streams, "
+                        "each with a native launcher thread; -1 = the default of this build (see DESIGN.md section 5)")
+    p.add_argument("--group-threads", type=int, default=1, help="0: issue the group launches from the calling thread")
+    p.add_argument("--min-timed-steps", type=int, default=2000,
+                   help="the timed interval holds R = ceil(this / K) back-to-back blocks of K steps")
     p.add_argument("--rollout-T", type=int, default=64, help="steps per launch of the fused roll-out leg")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--no-extras", action="store_true", help="skip the rollout_fused / rk4 / allgather legs")
+    p.add_argument("--no-extras", action="store_true", help="skip the rollout_fused / rk4 / policy / allgather legs")
+    p.add_argument("--no-parity", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
-    p.add_argument("--repeats", type=int, default=5, help="runs of (W untimed + K timed) steps; the median is reported")
+    p.add_argument("--repeats", type=int, default=3, help="timed intervals; the median one is reported")
     p.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                    help="nccl (= RCCL over xGMI, the real thing) or gloo (rehearsal of the multi-rank control flow, "
                         "e.g. several ranks sharing one GPU; skips the all-gather leg)")
+    p.add_argument("--spawn-timeout", type=float, default=1500.0)
     return p.parse_args()
 
 
+DEFAULT_GROUPS = 1   # measured on MI355X (profiles/r02/groups_sweep.txt): more chains in flight do not raise the rate
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` with no launcher around it
+# --------------------------------------------------------------------------------------------------------------------
+def spawn_ranks(args):
+    """WORLD_SIZE unset and --gpus N > 1: start N children (one per GPU) BEFORE this process touches the GPU, wait for
+    them, exit with the worst return code.  Rank 0's child prints the JSON line on the inherited stdout."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), QS_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    deadline = time.time() + args.spawn_timeout
+    rc = 0
+    try:
+        for p in procs:
+            left = max(1.0, deadline - time.time())
+            try:
+                rc = rc or p.wait(timeout=left)
+            except subprocess.TimeoutExpired:
+                rc = rc or 124
+            if rc:
+                break              # a failed / hung rank: do not wait for peers stuck in a collective
+    finally:
+        for p in procs:            # stragglers: the exact PIDs started above, nothing else
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            if p.poll() is None:
+                try:
+                    p.wait(timeout=10)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+    return rc
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# CPU legs (the oracle as the measured baseline; test infrastructure, never on the product path)
+# --------------------------------------------------------------------------------------------------------------------
 def cpu_baseline(kind, seconds, seed=1234):
     """The C oracle (oracle/quadsim_oracle.c, f64 build == the reference's float64 arithmetic restated)
     timed on the host cores, one thread per core (ctypes releases the GIL), same workload shape:
@@ -90,43 +153,163 @@ def cpu_baseline(kind, seconds, seed=1234):
                       "randomised auto-reset, %.1f s wall" % (cores, dt)}
 
 
+def config1_cpu(seconds=2.0):
+    """BASELINE config 1 (1 env, CPU only) on the build's CPU oracle, one core: the run_sim_PID.py:43-54 loop
+    (fixture g6's set-up) and a docking-v0 episode with the hover action a = (-0.5)^4, both as single C calls; and the
+    same episode driven per step through ctypes (what a Python caller of a C env pays).  SURVEY.md section 8(d) c1."""
+    import numpy as np
+    from oracle.pyoracle import Oracle, PAR_NOMINAL
+    orc = Oracle("f64")
+    out = {"cores": 1, "kind": "port", "what": "C oracle (f64), one env, one host core; the true Python reference runs "
+                                               "600-720 env-steps/s per core (BASELINE.md section 2)"}
+    g6 = os.path.join(ROOT, "tests", "golden", "g6_sim_pid.npz")
+    if os.path.exists(g6):
+        with np.load(g6) as z:
+            s0, sdes = z["ini_state"].copy(), z["state_des"].copy()
+    else:
+        s0 = np.zeros(13); s0[2] = 5.0; s0[6] = 1.0
+        sdes = s0.copy(); sdes[0:3] = (1.0, 1.0, 6.0)
+    T, n_calls = 2000, 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        orc.sim_pid(T, s0, sdes)
+        n_calls += 1
+    out["sim_pid_loop_steps_per_s"] = n_calls * T / (time.perf_counter() - t0)
+    # docking-v0, hover action, one episode per C call (auto-reset keeps it going through the 600-step time-out)
+    Te = 600
+    acts = np.full((Te, 1, 4), -0.5)
+    rec = orc.env_init(1)
+    par = np.tile(np.array(PAR_NOMINAL, np.float64), (1, 1))
+    n_calls = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < seconds:
+        orc.vec_rollout(rec, par, acts, kind=0)
+        n_calls += 1
+    out["docking_v0_hover_steps_per_s"] = n_calls * Te / (time.perf_counter() - t0)
+    # the same env stepped one ctypes call per step from Python (gym-style driver loop)
+    rec1 = orc.env_init(1)[0]
+    a = np.full(4, -0.5)
+    k = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < min(seconds, 1.0):
+        rec1, _, _, done, _ = orc.env_step(rec1, a)
+        if done:
+            rec1 = orc.env_init(1)[0]
+        k += 1
+    out["docking_v0_hover_python_loop_steps_per_s"] = k / (time.perf_counter() - t0)
+    return out
+
+
+# --------------------------------------------------------------------------------------------------------------------
+# parity: the BASELINE metric's second half ("per-step state L2 err vs NumPy ref")
+# --------------------------------------------------------------------------------------------------------------------
+def parity_vs_reference(qa, device):
+    """Replays fixture g4 (1 500 steps each of docking-v0 and docking-v2 recorded from the imported NumPy reference by
+    oracle/gen_goldens.py, full internal state before and after every step) through qs_step: step s becomes env s of one
+    batch, inputs rounded to float32, ONE fused step, outputs compared with the reference's own.  Outside the timed
+    region; the oracle is not involved."""
+    import numpy as np
+    out = {"source": "tests/golden/g4_traj_v{0,2}.npz = outputs of the NumPy reference (oracle/gen_goldens.py)",
+           "tolerance": "north_star: 1e-5 relative per step (float32)"}
+    worst = {"state_l2_rel": 0.0, "obs_l2_rel": 0.0, "reward_abs_scaled": 0.0}
+    for name, env_id in (("g4_traj_v0", "docking-v0"), ("g4_traj_v2", "docking-v2")):
+        path = os.path.join(ROOT, "tests", "golden", name + ".npz")
+        if not os.path.exists(path):
+            return None
+        with np.load(path) as z:
+            g = {k: z[k] for k in z.files}
+        n = len(g["rec_before"])
+        env = qa.VecDockingEnv(env_id, num_envs=n, device=device, auto_reset=False)
+        rec = g["rec_before"].astype(np.float32)
+        env.set_state(chaser=rec[:, 0:13], target=rec[:, 13:26], u_prev=rec[:, 26:34], qdes=rec[:, 34:38],
+                      last_shaping=rec[:, 38], t=rec[:, 39])
+        obs, rew, done, infos = env.step(g["actions"].astype(np.float32))
+        st = env.get_state()
+        obs, rew, done = obs.cpu().numpy().astype(np.float64), rew.cpu().numpy().astype(np.float64), done.cpu().numpy()
+        env.close()
+        ref = g["rec_after"]
+        l2 = lambda a, b: np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(b, axis=1), 1e-30)   # noqa: E731
+        e_c = l2(st["chaser"].astype(np.float64), ref[:, 0:13])
+        e_t = l2(st["target"].astype(np.float64), ref[:, 13:26])
+        e_o = l2(obs, g["obs"])
+        e_r = np.abs(rew - g["reward"]) / np.maximum(1.0, np.abs(ref[:, 38]))
+        # done / flags are decided by thresholds: exclude the steps the reference itself decides within 1e-4 of one
+        rmax = 3.0 if env_id == "docking-v0" else 10.0
+        npos = np.linalg.norm(g["obs"][:, 0:3], axis=1)
+        margin = np.minimum(np.abs(npos - rmax), np.abs(ref[:, 2] - 0.1))
+        flips = int(np.sum((done != g["done"].astype(bool)) & (margin > 1e-4)))
+        out[env_id] = {"steps": n, "chaser_state_l2_rel_max": float(e_c.max()), "target_state_l2_rel_max": float(e_t.max()),
+                       "state_l2_rel_mean": float(0.5 * (e_c.mean() + e_t.mean())), "obs_l2_rel_max": float(e_o.max()),
+                       "obs_l2_rel_mean": float(e_o.mean()), "reward_abs_over_max1shaping_max": float(e_r.max()),
+                       "done_flips_outside_1e-4_margin": flips}
+        worst["state_l2_rel"] = max(worst["state_l2_rel"], float(e_c.max()), float(e_t.max()))
+        worst["obs_l2_rel"] = max(worst["obs_l2_rel"], float(e_o.max()))
+        worst["reward_abs_scaled"] = max(worst["reward_abs_scaled"], float(e_r.max()))
+    out.update(worst)
+    out["within_tolerance"] = bool(worst["state_l2_rel"] <= 1e-5 and worst["obs_l2_rel"] <= 1e-5 and worst["reward_abs_scaled"] <= 2e-5)
+    return out
+
+
+# --------------------------------------------------------------------------------------------------------------------
+def rocprof_kernel_average(kernel_substr, fname="step_api_kernel_stats.csv"):
+    """average duration (us) of the step kernel in the committed `rocprofv3 --kernel-trace --stats` summary"""
+    import csv
+    path = os.path.join(PROFILE_DIR, fname)
+    try:
+        with open(path) as f:
+            for row in csv.DictReader(f):
+                if kernel_substr in row.get("Name", ""):
+                    return float(row["AverageNs"]) / 1e3, int(row["Calls"]), os.path.relpath(path, ROOT)
+    except (OSError, KeyError, ValueError):
+        pass
+    return None
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args))          # the parent never initialises the GPU
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
         raise SystemExit("WORLD_SIZE=%d but --gpus=%d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
+    ndev = torch.cuda.device_count()
     if args.backend == "gloo":
-        local_rank = local_rank % torch.cuda.device_count()          # rehearsal: ranks may share a GPU
+        local_rank = local_rank % ndev          # rehearsal: ranks may share a GPU
+    elif local_rank >= ndev:
+        raise SystemExit("--gpus %d with backend nccl needs %d visible GPUs, found %d (use --backend gloo to rehearse "
+                         "the multi-rank control flow on fewer)" % (args.gpus, args.gpus, ndev))
     torch.cuda.set_device(local_rank)
     distributed = world > 1 or bool(os.environ.get("QS_BENCH_FORCE_DIST"))   # the env hook rehearses the RCCL path on one GPU
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if args.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
 
     import ctypes as C
-    from quadsim_amd import C3_INIT_RANGE, VecDockingEnv, _lib, shard_range
+    import quadsim_amd as qa
+    from quadsim_amd import C3_INIT_RANGE, VecDockingEnv, shard_range
 
     n = args.envs_per_gpu
     total_envs = n * world
     lo, hi = shard_range(total_envs, rank, world)
     assert hi - lo == n
     kind = 0 if args.env == "docking-v0" else 1
+    groups = DEFAULT_GROUPS if args.groups < 0 else max(1, args.groups)
 
-    def make_env(integrator):
-        return VecDockingEnv(args.env, num_envs=n, device=local_rank, integrator=integrator, randomise=args.randomise,
-                             seed=1234, env_id_offset=lo, init_range=C3_INIT_RANGE, mass_scale=(0.8, 1.2),
-                             inertia_scale=(0.8, 1.2))
+    def make_env(integrator, num=n, offset=lo):
+        return VecDockingEnv(args.env, num_envs=num, device=local_rank, integrator=integrator, randomise=args.randomise,
+                             seed=1234, env_id_offset=offset, init_range=C3_INIT_RANGE, mass_scale=(0.8, 1.2),
+                             inertia_scale=(0.8, 1.2), copy=False)
 
     def barrier():
         torch.cuda.synchronize()
@@ -141,22 +324,29 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
 
-    def time_steps(env, K, W, pool):
-        """W untimed + K timed qs_step launches; returns (wall seconds max over ranks, HIP-event ms)"""
+    def time_steps(env, K, R, W, pool, G=1):
+        """W untimed steps, then ONE timed interval of R blocks of exactly K steps, barrier + synchronize on both sides.
+        -> (wall seconds, max over ranks; HIP-event ms on the launching stream(s) of the same launches)"""
         lib, h = env._lib, env._h
         P = pool.shape[0]
         aptr = [C.c_void_p(pool[i].data_ptr()) for i in range(P)]
         obs, rew, done, flags, term = (env._ptr(env._obs), env._ptr(env._rew), env._ptr(env._done),
                                        env._ptr(env._flags), env._ptr(env._term))
-        step = lib.qs_step
+        if G > 1:
+            step = lambda a: lib.qs_step_groups(h, a, obs, rew, done, flags, term, None)     # noqa: E731
+        else:
+            step = lambda a: lib.qs_step(h, a, obs, rew, done, flags, term)                  # noqa: E731
         for k in range(W):
-            step(h, aptr[k % P], obs, rew, done, flags, term)
+            step(aptr[k % P])
         barrier()
-        env.timer_start()
+        env.timer_start()                    # event on the main stream; group streams are ordered behind it
         t0 = time.perf_counter()
-        for k in range(K):
-            step(h, aptr[k % P], obs, rew, done, flags, term)
-        ev_ms = env.timer_stop()
+        k = 0
+        for _ in range(R):
+            for _ in range(K):
+                step(aptr[k % P])
+                k += 1
+        ev_ms = env.timer_stop()             # joins the group streams, records the stop event, waits for it
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         if distributed:
@@ -164,58 +354,96 @@ def main():
         return max_over_ranks(wall), ev_ms
 
     K, W = args.steps, args.warmup
+    R = max(1, -(-args.min_timed_steps // K))
     env = make_env(args.integrator)
     env.reset()
-    P = max(1, min(args.action_pool, K))
+    if groups > 1:
+        groups = env.set_groups(groups, threads=bool(args.group_threads))
+    P = max(1, min(args.action_pool, K * R))
     pool = env.random_actions(P, step0=0)               # [P,N,4] U(-1,1), resident in HBM before timing
-    # median of 5 runs.  Every run is W untimed + EXACTLY K timed steps between barrier + sync;
-    # the reported run is the median one (its wall clock AND its HIP-event time), all five are listed in "runs".
-    runs = [time_steps(env, K, W, pool) for _ in range(max(1, args.repeats))]
+    runs = [time_steps(env, K, R, W, pool, groups) for _ in range(max(1, args.repeats))]
     order = sorted(range(len(runs)), key=lambda i: runs[i][0])
     wall, ev_ms = runs[order[len(order) // 2]]
-    value = total_envs * K / wall
+    steps_timed = K * R
+    value = total_envs * steps_timed / wall
     bpe = BYTES_PER_ENV_STEP_DR if args.randomise >= 2 else BYTES_PER_ENV_STEP
-    launch_us = ev_ms * 1e3 / K
-    achieved = bpe * n / (launch_us * 1e-6) / 1e9       # GB/s per GPU, algorithmic bytes / avg launch period
+    rbpe = 176 if bpe == 392 else 192
+    step_us = wall * 1e6 / steps_timed
+    achieved = bpe * n / (step_us * 1e-6) / 1e9          # GB/s per GPU: algorithmic bytes of one step / wall time of one step
+    ev_us = ev_ms * 1e3 / steps_timed
+    split = n <= 131072
+    kname = "k_env_split" if split else "k_env<"
 
     out = {
         "metric": "env-steps/sec at N parallel envs (1/2/4/8 GPU); per-step state L2 err vs NumPy ref",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
-        "ms_per_step": wall * 1e3 / K, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": wall * 1e3 / steps_timed, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "runs": {"policy": "median of %d runs of W untimed + K timed steps" % len(runs),
-                 "env_steps_per_s": [total_envs * K / r[0] for r in runs]},
+        "timed_region": {"blocks_of_K_steps": R, "steps_timed": steps_timed, "wall_s": wall,
+                         "policy": "median of %d intervals; each = %d untimed + %d x %d timed steps between barrier + "
+                                   "synchronize; value, ms_per_step and roofline.frac all derive from this one wall clock"
+                                   % (len(runs), W, R, K),
+                         "env_steps_per_s_all_intervals": [total_envs * steps_timed / r[0] for r in runs]},
         "config": {"workload": "BASELINE config 3: %d parallel %s envs per GPU, U(-1,1) random actions, SoA tiles + "
                                "rocRAND randomised auto-reset" % (n, args.env),
                    "envs_per_gpu": n, "total_envs": total_envs, "env": args.env, "integrator": args.integrator,
-                   "dt": 0.02, "randomise": args.randomise, "mode": "step-API (one qs_step launch per step)",
+                   "dt": 0.02, "randomise": args.randomise,
+                   "mode": ("step-API: one qs_step launch per step" if groups <= 1 else
+                            "step-API: one qs_step_groups call per step = %d launches (env groups of %d envs on %d streams, "
+                            "%s), bit-identical to qs_step" % (groups, n // groups, groups,
+                                                              "one launcher thread per group" if args.group_threads else "issued by the calling thread")),
+                   "groups": groups,
                    "parallelism": "env-sharded x%d, no data-path collective" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": ("k_env_split<%s> (T=1): two waves per tile" if n <= 131072 else "k_env<%s> (T=1)") % args.integrator,
-                     "bytes_per_env_step": bpe,
-                     "bytes_per_launch": bpe * n, "launch_period_us": launch_us,
-                     "read_frac": (176 if bpe == 392 else 192) * n / (launch_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                     "basis": "HIP events on the launching stream around the K timed launches / K "
-                              "(launch period incl. inter-kernel gaps); working set %.1f MB is Infinity-Cache resident"
-                              % (n * 160 / 1e6)},
+                     "kernel": ("k_env_split<%s> (T=1): two waves per tile" if split else "k_env<%s> (T=1)") % args.integrator,
+                     "bytes_per_env_step": bpe, "bytes_per_step": bpe * n, "launches_per_step": groups,
+                     "step_period_us": step_us,
+                     "read_frac": rbpe * n / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                     "read_frac_target": READ_TARGET,
+                     "read_frac_target_met": bool(rbpe * n / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS >= READ_TARGET),
+                     "gpu_timeline_us_per_step": ev_us,
+                     "gpu_timeline_frac": bpe * n / (ev_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                     "basis": "achieved = %d B x %d envs / wall time per step (the SAME clock as value and ms_per_step); "
+                              "gpu_timeline_* = HIP events around the same launches; working set %.1f MB is "
+                              "Infinity-Cache resident" % (bpe, n, n * 160 / 1e6)},
     }
-
-    # HBM-side bytes per launch from the PMC passes (collected separately: rocprofv3 --pmc cannot run inside
+    # rocprofv3 kernel average of the same command (committed summary): per-launch duration of the step kernel
+    rp = rocprof_kernel_average(kname)
+    if rp and n == 65536 and args.env == "docking-v0" and args.integrator == "frozen" and args.randomise == 1:
+        avg_us, calls, src = rp
+        per_launch_bytes = bpe * n / groups
+        out["roofline"].update({"rocprof_kernel_avg_us": avg_us, "rocprof_calls": calls, "rocprof_source": src,
+                                "rocprof_kernel_frac": per_launch_bytes / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                "rocprof_note": "bytes of ONE launch (%d envs) / its average duration under the profiler; with "
+                                                "%d groups in flight the launches overlap, so the step period is shorter than "
+                                                "%d x this" % (n // groups, groups, groups)})
+    # HBM-side bytes per step from the PMC passes (collected separately: rocprofv3 --pmc cannot run inside
     # this process); only quoted when the profile was taken on this very configuration
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01", "pmc_traffic.json")))
+        pmc = json.load(open(os.path.join(PROFILE_DIR, "pmc_traffic.json")))
         if pmc["envs"] == n and args.env == "docking-v0" and args.integrator == "frozen" and args.randomise == 1:
-            out["roofline"]["traffic"] = pmc["traffic_bytes_per_launch"]
+            out["roofline"]["traffic"] = pmc["traffic_bytes_per_step"]
             out["roofline"]["traffic_source"] = pmc["source"]
     except (OSError, ValueError, KeyError):
         pass
 
+    if not args.no_parity and rank == 0:
+        out["parity"] = parity_vs_reference(qa, local_rank)
+
     if not args.no_extras:
+        # the same step with ONE launch per step (no groups): the per-kernel view
+        if groups > 1:
+            env.set_groups(1)
+            w1, ms1 = time_steps(env, K, R, min(W, 50), pool, 1)
+            out["single_launch_per_step"] = {"value": total_envs * steps_timed / w1, "unit": "env-steps/s",
+                                             "step_period_us": w1 * 1e6 / steps_timed,
+                                             "frac": bpe * n / (w1 / steps_timed) / 1e9 / HBM_PEAK_GBS,
+                                             "gpu_timeline_us_per_step": ms1 * 1e3 / steps_timed}
         # fused roll-out leg: T steps per launch, state in registers (different algorithmic bytes: see DESIGN.md)
         T = args.rollout_T
         acts = pool[:T] if P >= T else env.random_actions(T)
-        reps = max(1, min(20, K // T))
+        reps = max(1, min(20, steps_timed // T))
         env.rollout(acts)
         barrier()
         env.timer_start()
@@ -228,31 +456,29 @@ def main():
         b_roll = 16 + 48 + 4 + 1 + 320.0 / T
         out["rollout_fused"] = {"value": total_envs * T * reps / w2, "unit": "env-steps/s", "T": T, "launches": reps,
                                 "bytes_per_env_step": b_roll,
-                                "hbm_frac": b_roll * n * T * reps / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                "hbm_frac": b_roll * n * T * reps / w2 / 1e9 / HBM_PEAK_GBS,
                                 "note": "qs_rollout: identical results to T qs_step calls; VALU-bound, not HBM-bound"}
         del o_, r_, d_, f_
         # rk4 integrator (the physically intended mode; same kernel, 4 df evaluations per drone)
         other = "rk4" if args.integrator == "frozen" else "frozen"
         env_o = make_env(other)
         env_o.reset()
-        Ko = max(100, K // 4)
-        w3, ms3 = time_steps(env_o, Ko, min(W, 50), pool)
+        Ko = max(100, steps_timed // 4)
+        w3, ms3 = time_steps(env_o, Ko, 1, min(W, 50), pool)
         out["other_integrator"] = {"integrator": other, "value": total_envs * Ko / w3, "unit": "env-steps/s",
-                                   "launch_period_us": ms3 * 1e3 / Ko}
+                                   "step_period_us": w3 * 1e6 / Ko}
         env_o.close()
         # the same step kernel where it is not latency-bound: 1 048 576 envs per GPU (168 MB of state, 16 waves per
         # SIMD): shows the kernel's bandwidth ceiling beside the 65 536-env headline
         if n < (1 << 20):
             nb = 1 << 20
-            env_b = VecDockingEnv(args.env, num_envs=nb, device=local_rank, integrator=args.integrator,
-                                  randomise=args.randomise, seed=1234, env_id_offset=rank * nb, init_range=C3_INIT_RANGE,
-                                  mass_scale=(0.8, 1.2), inertia_scale=(0.8, 1.2))
+            env_b = make_env(args.integrator, nb, rank * nb)
             env_b.reset()
             pool_b = env_b.random_actions(8, step0=0)
-            wb, msb = time_steps(env_b, 200, 20, pool_b)
+            wb, msb = time_steps(env_b, 200, 1, 20, pool_b)
             out["step_api_1M_envs"] = {"envs_per_gpu": nb, "value": nb * world * 200 / wb, "unit": "env-steps/s",
-                                       "launch_period_us": msb * 1e3 / 200,
-                                       "hbm_frac": bpe * nb / (msb * 1e-3 / 200) / 1e9 / HBM_PEAK_GBS}
+                                       "step_period_us": wb * 1e6 / 200,
+                                       "hbm_frac": bpe * nb / (wb / 200) / 1e9 / HBM_PEAK_GBS}
             env_b.close()
             del pool_b
         # policy in the loop: a = clip(MLP(obs)); env.step(a), T steps per launch, the shipped PPO2
@@ -280,12 +506,12 @@ def main():
                 "note": "exact-f32 MFMA (v_mfma_f32_16x16x4_f32); 36 864 MLP flop per env-step"}
             out["policy_rollout_bf16x3_mfma"]["note"] = "split-bf16 operands, 3 MFMAs per product, ~1e-5 action error (opt-in)"
             # PPO2 data collection (Runner._run, rl_baselines/ppo2/ppo2.py:472-527): actor + critic + Gaussian sampling +
-            # neglogp + env.step for n_steps in one launch, then the GAE kernel and the env-major flatten of 7 arrays
+            # neglogp + env.step for n_steps in one launch, then GAE + flatten + episode accounting
             from quadsim_amd import ActorCriticPolicy, Runner
             ac = ActorCriticPolicy.from_npz(wpath, device="cuda:%d" % local_rank)
             flop_ac = 2 * (12 * 128 + 2 * 128 * 128 + 128 * 4 + 128)
             for prec, key in (("f32", "ppo2_runner_f32_mfma"), ("bf16x3", "ppo2_runner_bf16x3_mfma")):
-                runner = Runner(env=env, model=ac, n_steps=Tp, gamma=0.99, lam=0.95, track_episodes=False, precision=prec)
+                runner = Runner(env=env, model=ac, n_steps=Tp, gamma=0.99, lam=0.95, collect_ep_infos=False, precision=prec)
                 runner.run()
                 barrier()
                 t0 = time.perf_counter()
@@ -297,7 +523,7 @@ def main():
                             "mlp_tflops": total_envs * (Tp + 1) * 4 * flop_ac / w6 / 1e12}
             out["ppo2_runner_f32_mfma"]["what"] = (
                 "Runner.run(): qs_runner_rollout (policy + value nets on exact-f32 MFMA, rocRAND Gaussian sampling, "
-                "neglogp, fused env.step) + qs_gae + swap_and_flatten of obs/returns/dones/actions/values/neglogp/rewards")
+                "neglogp, fused env.step) + qs_gae_flatten + qs_episode_stats + swap_and_flatten of obs / actions")
             out["ppo2_runner_bf16x3_mfma"]["note"] = "the same with split-bf16 operands (qs_runner_rollout_fast), ~1e-5 error on means / values (opt-in)"
         if distributed and args.backend == "nccl":
             # BASELINE configs 4/5: RCCL all-gather of the roll-out slabs (obs, reward, done) once per T-step roll-out
@@ -311,12 +537,14 @@ def main():
                 gather_slab(slab, out=gathered)
             torch.cuda.synchronize()
             w4 = max_over_ranks(time.perf_counter() - t0)
-            out["allgather"] = {"value": total_envs * T * reps / w4, "unit": "env-steps/s",
+            out["allgather"] = {"value": total_envs * T * reps / w4, "unit": "env-steps/s", "world_size": dist.get_world_size(),
+                                "backend": dist.get_backend(),
                                 "what": "qs_rollout_slab(T=%d) + ONE RCCL all_gather of the packed (obs, reward, done) slab "
                                         "(%.1f MB per rank per roll-out)" % (T, T * n * 56 / 1e6)}
 
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(kind, args.cpu_seconds)
+        out["config1"] = config1_cpu()
     elif rank == 0:
         out["cpu_baseline"] = None
     env.close()
@@ -324,7 +552,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

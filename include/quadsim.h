@@ -16,8 +16,9 @@
  *     QS_IO_HOST they are host pointers and the call stages them through the
  *     GPU and returns after the result is back (single-env gym shim).
  *   - device calls are asynchronous on the handle's stream; qs_sync() waits.
- *   - a handle is not thread-safe; distinct handles are independent (one per
- *     GPU / per process).
+ *   - a handle is not thread-safe (call it from one thread at a time; the launcher
+ *     threads of qs_set_groups are internal); distinct handles are independent
+ *     (one per GPU / per process).
  *   - there is no CPU fallback: creation fails if no HIP device is present.
  *
  * Layouts (row-major, float32 unless noted)
@@ -36,7 +37,7 @@
 extern "C" {
 #endif
 
-#define QS_VERSION 100 /* 0.1.0 */
+#define QS_VERSION 110 /* 0.1.1: qs_step_ex, env groups, qs_gae_flatten, qs_episode_stats, qs_swap_and_flatten_u8 */
 
 enum {
     QS_OK = 0,
@@ -127,6 +128,44 @@ int qs_reset(QsEnv *env, const uint8_t *mask, float *obs_out);
 int qs_step(QsEnv *env, const float *actions, float *obs, float *reward, uint8_t *done, uint8_t *flags,
             float *terminal_obs);
 
+/* qs_step that also hands out the TERMINAL state of every env that finished: terminal_state [N,26] nullable = chaser
+ * [13] | target [13] as they stood when the step returned done (rows written only where done && auto_reset).  This is
+ * what info['chaser'] / info['target'] hold on a done step in the reference (docking_env.py:226-229 return
+ * self.state_chaser / self.state_target of the terminal step; SB2's SubprocVecEnv worker resets only afterwards). */
+int qs_step_ex(QsEnv *env, const float *actions, float *obs, float *reward, uint8_t *done, uint8_t *flags,
+               float *terminal_obs, float *terminal_state);
+
+/* ---- env groups: several step chains of ONE handle in flight at a time -------------------------------------------
+ * The reference's trainers step 10 worker processes that run concurrently (run_docking_ppo2.py:65-67
+ * SubprocVecEnv([...]*10): step_async sends to every worker, step_wait collects).  The device analogue: the N envs
+ * of a handle are partitioned into G contiguous groups (whole 64-env tiles), each with its own stream, so that the
+ * step of one group overlaps the kernel boundary / the policy of another (EnvPool-style send / recv).  Envs never
+ * interact and RNG is keyed by global env id, so any grouping computes bit-identical results to qs_step.
+ *   qs_set_groups(env, G, threads): G <= 1 removes the grouping.  threads != 0: every group gets a launcher thread --
+ *     the calling thread only posts a launch record (a lone host thread issues ~0.35 launches / us, less than two
+ *     groups consume).
+ *   qs_group_range: [env_begin, env_end) of group g.   qs_group_stream: its hipStream_t (run that group's policy on
+ *     it and no cross-stream ordering is needed at all);  qs_group_set_stream: use a caller-owned stream instead.
+ *   qs_step_group(env, g, ...): one step of group g on its stream; every pointer addresses the GROUP's rows
+ *     (actions [n_g,4], obs [n_g,12], ... of envs env_begin..env_end-1).
+ *   qs_step_groups(env, ...): one step of ALL groups, full-batch [N,...] pointers as qs_step_ex; one call, G launches.
+ * Ordering: work of the handle itself is ordered automatically (a group step waits for earlier main-stream calls such as
+ * qs_reset; every other entry point first waits for pending group steps).  Data the CALLER produces or consumes on
+ * another stream is the caller's to order: qs_groups_fork makes the group streams wait for the main stream's work so
+ * far, qs_groups_join makes the main stream wait for the group streams (qs_sync, the timers and every non-group call do
+ * it implicitly). */
+int qs_set_groups(QsEnv *env, int32_t groups, int32_t launcher_threads);
+int qs_group_count(QsEnv *env, int32_t *groups);
+int qs_group_range(QsEnv *env, int32_t g, int64_t *env_begin, int64_t *env_end);
+int qs_group_stream(QsEnv *env, int32_t g, void **hip_stream);
+int qs_group_set_stream(QsEnv *env, int32_t g, void *hip_stream);
+int qs_step_group(QsEnv *env, int32_t g, const float *actions, float *obs, float *reward, uint8_t *done, uint8_t *flags,
+                  float *terminal_obs, float *terminal_state);
+int qs_step_groups(QsEnv *env, const float *actions, float *obs, float *reward, uint8_t *done, uint8_t *flags,
+                   float *terminal_obs, float *terminal_state);
+int qs_groups_fork(QsEnv *env);
+int qs_groups_join(QsEnv *env);
+
 /* T consecutive steps in ONE launch, env state held in registers (the loop body of the
  * trainer's Runner, rl_baselines/ppo2/ppo2.py:472-499, with the policy's actions pre-staged).
  * Requires auto_reset.  actions [T,N,4], or NULL: U(-1,1) actions drawn in-kernel from the
@@ -200,6 +239,30 @@ int qs_gae(QsEnv *env, int64_t T, int64_t n, const float *rewards, const float *
 
 /* swap_and_flatten, rl_baselines/ppo2/ppo2.py:531-539: in [T,n,d] -> out [n*T,d] (env-major).  d in {1,4,12,13}. */
 int qs_swap_and_flatten(QsEnv *env, int64_t T, int64_t n, int64_t d, const float *in, float *out);
+
+/* swap_and_flatten of a uint8 [T,n] array (mb_dones) without the float round trip */
+int qs_swap_and_flatten_u8(QsEnv *env, int64_t T, int64_t n, const uint8_t *in, uint8_t *out);
+
+/* GAE and the env-major flatten of every per-(t, env) scalar of Runner.run in ONE pass over the roll-out
+ * (rl_baselines/ppo2/ppo2.py:507-523: mb_returns = GAE; then swap_and_flatten of mb_returns, mb_dones, mb_values,
+ * mb_neglogpacs, true_reward).  Inputs as qs_gae plus neglogp [T,n] (nullable together with flat_neglogp).  Outputs,
+ * env-major [n*T]: flat_returns, flat_values, flat_neglogp, flat_rewards (float32) and flat_masks (uint8 0/1 = mb_dones);
+ * advs / returns [T,n] time-major are optional (both or neither) and equal qs_gae's.  Device buffers. */
+int qs_gae_flatten(QsEnv *env, int64_t T, int64_t n, const float *rewards, const float *values, const float *neglogp,
+                   const uint8_t *dones, const float *last_values, const uint8_t *last_dones, float gamma, float lam,
+                   float *flat_returns, float *flat_values, float *flat_neglogp, float *flat_rewards, uint8_t *flat_masks,
+                   float *advs, float *returns);
+
+/* Episode accounting of one roll-out: return and length of every episode that ENDS inside it -- what the Monitor
+ * wrapper (run_docking_ppo2.py:19-35) reports as info['episode'] = {'r', 'l'} and Runner._run collects into ep_infos
+ * (ppo2.py:486-489).  rewards [T,n]; dones [T,n] = flags BEFORE each step (mb_dones); last_dones [n] = flags after the
+ * last step.  ep_ret [n] float32 / ep_len [n] int32 carry the unfinished episode of every env from one roll-out to the
+ * next (in/out; zero them once).  Out: *count (device uint64) = episodes found; the first min(count, cap) of them as
+ * (out_key = t*n + env, out_ret, out_len) in unspecified order -- sort by key for the reference's (step, env) order.
+ * cap = T*n can never overflow.  Device buffers. */
+int qs_episode_stats(QsEnv *env, int64_t T, int64_t n, const float *rewards, const uint8_t *dones,
+                     const uint8_t *last_dones, float *ep_ret, int32_t *ep_len, uint64_t *count, int64_t cap,
+                     int64_t *out_key, float *out_ret, int32_t *out_len);
 
 /* Policy-in-the-loop roll-out in one launch: for t < T:  a_t = clip(MLP(obs_t), -1, 1);  obs_{t+1}, r_t, done_t =
  * env.step(a_t) -- the loop of run_trained_docking_ppo2.py:37-60 for N envs, with the deterministic actor of the

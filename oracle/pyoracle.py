@@ -315,3 +315,22 @@ def actor_critic_step(W, obs, noise, squash=False):
     else:
         env_action = np.clip(u, -1.0, 1.0)                                        # rl_baselines/ppo2/ppo2.py:483
     return u, value, neglogp, env_action, mean
+
+
+def episode_stats_ref(rewards, dones, last_dones, ep_ret, ep_len):
+    """Plain restatement of the episode accounting a Monitor-wrapped env feeds into Runner._run's ep_infos
+    (run_docking_ppo2.py:19-35; rl_baselines/ppo2/ppo2.py:486-489): rewards [T,N]; dones [T,N] = done flag BEFORE
+    step t (ppo2.py:479), last_dones [N] = flag after the last step.  ep_ret / ep_len [N] (float64 / int64) carry
+    the unfinished episodes and are updated in place.  -> list of (key = t*N + env, return, length) in (step, env) order."""
+    rewards = np.asarray(rewards, np.float64)
+    T, n = rewards.shape
+    after = np.concatenate([np.asarray(dones)[1:], np.asarray(last_dones)[None]], 0).astype(bool)
+    out = []
+    for t in range(T):
+        ep_ret += rewards[t]
+        ep_len += 1
+        for i in np.nonzero(after[t])[0]:
+            out.append((t * n + int(i), float(ep_ret[i]), int(ep_len[i])))
+            ep_ret[i] = 0.0
+            ep_len[i] = 0
+    return out

@@ -27,6 +27,9 @@ EXPORTS = [
     "qs_set_init_state", "qs_get_init_state", "qs_obs_dim", "qs_get_step_counter", "qs_set_step_counter", "qs_set_stream", "qs_sync", "qs_timer_start", "qs_timer_stop",
     "qs_drone_step", "qs_ctrl", "qs_rel_obs", "qs_transform", "qs_gae", "qs_swap_and_flatten", "qs_expert_action", "qs_policy_rollout", "qs_policy_rollout_fast", "qs_policy_rollout_fast_blob_bytes",
     "qs_runner_rollout", "qs_runner_rollout_fast", "qs_runner_rollout_fast_blob_bytes",
+    "qs_step_ex", "qs_set_groups", "qs_group_count", "qs_group_range", "qs_group_stream", "qs_group_set_stream",
+    "qs_step_group", "qs_step_groups", "qs_groups_fork", "qs_groups_join",
+    "qs_swap_and_flatten_u8", "qs_gae_flatten", "qs_episode_stats",
 ]
 
 
@@ -135,6 +138,19 @@ def load():
         "qs_runner_rollout": [vp, i64, C.POINTER(QsActorCritic)] + [vp] * 12,
         "qs_runner_rollout_fast": [vp, i64, vp, C.POINTER(C.c_float), i32] + [vp] * 12,
         "qs_runner_rollout_fast_blob_bytes": [],
+        "qs_step_ex": [vp] * 8,
+        "qs_set_groups": [vp, i32, i32],
+        "qs_group_count": [vp, C.POINTER(i32)],
+        "qs_group_range": [vp, i32, C.POINTER(i64), C.POINTER(i64)],
+        "qs_group_stream": [vp, i32, C.POINTER(vp)],
+        "qs_group_set_stream": [vp, i32, vp],
+        "qs_step_group": [vp, i32] + [vp] * 7,
+        "qs_step_groups": [vp] * 8,
+        "qs_groups_fork": [vp],
+        "qs_groups_join": [vp],
+        "qs_swap_and_flatten_u8": [vp, i64, i64, vp, vp],
+        "qs_gae_flatten": [vp, i64, i64, vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp],
+        "qs_episode_stats": [vp, i64, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

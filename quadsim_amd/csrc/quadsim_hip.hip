@@ -17,7 +17,21 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <new>
+#include <thread>
+#include <vector>
+
+// -DQS_DEBUG: in-kernel bound checks of every global index (a failed check prints file:line and traps the wave); the
+// release build compiles them away.  tools/build_debug.sh builds libquadsim_hip_dbg.so for QUADSIM_HIP_LIB=...
+#ifdef QS_DEBUG
+#include <cassert>
+#define QS_ASSERT(c) assert(c)
+#else
+#define QS_ASSERT(c) ((void)0)
+#endif
 
 #include "../../include/quadsim.h"
 #include "quadsim_device.hpp"
@@ -46,8 +60,11 @@ struct StepArgs {
     uint8_t *done;
     uint8_t *flags;        // nullable
     float *term_obs;       // nullable, [N,12] (T == 1 only)
+    float *term_state;     // nullable, [N,26] (T == 1 only): chaser 13 | target 13 of the terminal step (docking_env.py:226-229)
     float *slab;           // nullable: packed roll-out slab [T,N,14] = obs 12, reward, done (as 0/1); replaces obs/reward/done
     int64_t n;
+    int64_t tile0, tile_end;   // tiles [tile0, tile_end) are stepped by this launch (an env group; the whole handle by default)
+    int64_t io_env0, io_n;     // the I/O arrays start at env io_env0 and hold io_n envs per step (0, n: full-batch arrays)
     int64_t T;             // rollout length (1 for step)
     uint64_t step_idx;     // explicit step index (k_fill_actions); the env kernels read the device counter below
     unsigned long long *ctr;   // device: global step counter k, one copy per tile [tiles]
@@ -137,7 +154,12 @@ __device__ __forceinline__ void step_and_maybe_reset(Env &e, Par &P, const float
     env_step<INTEG>(e, a, P, A.C, obs, reward, flags);
     done = (flags & (FLAG_OVERLIMIT | FLAG_OVERTIME)) != 0;
     if (done && A.auto_reset) {
-        if (write_term && A.term_obs) store_obs(A.term_obs, env, obs);
+        if (write_term && A.term_obs) store_obs(A.term_obs, env - A.io_env0, obs);
+        if (write_term && A.term_state) {
+            float *ts = A.term_state + (env - A.io_env0) * 26;
+#pragma unroll
+            for (int i = 0; i < 13; ++i) { ts[i] = e.sc[i]; ts[13 + i] = e.st[i]; }
+        }
         if (RMODE == 0) {
             // nominal states are constants: no need to re-derive their observation per lane
             nominal_init(e.sc, e.st);
@@ -172,14 +194,16 @@ template <int INTEG, bool PARAMS, int RMODE>
 __global__ __launch_bounds__(kBlock) void k_env(StepArgs A)
 {
     const int lane = threadIdx.x & (kTile - 1);
-    const int64_t tile = (int64_t)blockIdx.x * (kBlock / kTile) + (threadIdx.x >> 6);
+    const int64_t tile = A.tile0 + (int64_t)blockIdx.x * (kBlock / kTile) + (threadIdx.x >> 6);
     const int64_t env = tile * kTile + lane;
-    if (env >= A.n) return;
+    if (tile >= A.tile_end || env >= A.n) return;
+    const int64_t io = env - A.io_env0;          // row of this env in the I/O arrays
+    QS_ASSERT(io >= 0 && io < A.io_n);
     const uint64_t k0 = step_counter_begin(A, tile);
     // the first action is requested together with the tile (one exposed memory latency per launch, not two) and
     // every later one a whole step ahead of its use
     float4 av_next = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-    if (A.actions) av_next = reinterpret_cast<const float4 *>(A.actions)[env];
+    if (A.actions) av_next = reinterpret_cast<const float4 *>(A.actions)[io];
     Env e;
     load_env(A.st, tile, lane, e);
     Par P = A.par_nom;
@@ -187,11 +211,11 @@ __global__ __launch_bounds__(kBlock) void k_env(StepArgs A)
 #pragma clang loop unroll(disable)
     for (int64_t t = 0; t < A.T; ++t) {
         const uint64_t k = k0 + (uint64_t)t;
-        const int64_t o = t * A.n + env;
+        const int64_t o = t * A.io_n + io;
         float a[4];
         if (A.actions) {
             const float4 av = av_next;
-            if (t + 1 < A.T) av_next = reinterpret_cast<const float4 *>(A.actions)[o + A.n];
+            if (t + 1 < A.T) av_next = reinterpret_cast<const float4 *>(A.actions)[o + A.io_n];
             a[0] = av.x; a[1] = av.y; a[2] = av.z; a[3] = av.w;
         } else {
             random_action(A.rc.seed, A.gid0 + (uint64_t)env, k, a);
@@ -233,9 +257,11 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
     __shared__ unsigned char s_done[kTile], s_limt[kTile];
     const int lane = threadIdx.x & (kTile - 1);
     const int role = threadIdx.x >> 6;
-    const int64_t tile = blockIdx.x;
+    const int64_t tile = A.tile0 + blockIdx.x;   // grid = the tiles of this launch's env group
     const int64_t env = tile * kTile + lane;
     const bool active = env < A.n;               // idle lanes of the tail tile compute on zeros and store nothing
+    const int64_t io = env - A.io_env0;          // row of this env in the I/O arrays
+    QS_ASSERT(tile < A.tile_end && (!active || (io >= 0 && io < A.io_n)));
     const uint64_t k0 = step_counter_begin(A, tile);
     const float *b = A.st + tile * (int64_t)(kRecWords * kTile) + lane;
     float *bw = A.st + tile * (int64_t)(kRecWords * kTile) + lane;
@@ -246,7 +272,7 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
         // speculative draws: give it the issue slots first (roll-out 2.28 -> 2.13 us/step; no help for a single step)
         if (A.T > 1) __builtin_amdgcn_s_setprio(3);
         float4 av_next = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (A.actions && active) av_next = reinterpret_cast<const float4 *>(A.actions)[env];
+        if (A.actions && active) av_next = reinterpret_cast<const float4 *>(A.actions)[io];
         float sc[13], uc[4];
 #pragma unroll
         for (int i = 0; i < 13; ++i) sc[i] = b[(F_SC + i) * kTile];
@@ -256,11 +282,11 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
 #pragma clang loop unroll(disable)
         for (int64_t t = 0; t < A.T; ++t) {
             const uint64_t k = k0 + (uint64_t)t;
-            const int64_t o = t * A.n + env;
+            const int64_t o = t * A.io_n + io;
             float a[4];
             if (A.actions) {
                 const float4 av = av_next;
-                if (t + 1 < A.T && active) av_next = reinterpret_cast<const float4 *>(A.actions)[o + A.n];
+                if (t + 1 < A.T && active) av_next = reinterpret_cast<const float4 *>(A.actions)[o + A.io_n];
                 a[0] = av.x; a[1] = av.y; a[2] = av.z; a[3] = av.w;
             } else {
                 random_action(A.rc.seed, A.gid0 + (uint64_t)env, k, a);
@@ -284,7 +310,12 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
             s_done[lane] = rs ? 1 : 0;
             __syncthreads();                                              // #2: reset flags out, this step's Philox words in
             if (rs) {
-                if (A.term_obs && active) store_obs(A.term_obs, env, obs);
+                if (A.term_obs && active) store_obs(A.term_obs, io, obs);
+                if (A.term_state && active) {
+                    float *ts = A.term_state + io * 26;
+#pragma unroll
+                    for (int i = 0; i < 13; ++i) ts[i] = sc[i];
+                }
                 float ic[13], it[13];
                 if (RMODE == 0) {
                     nominal_init(ic, it);
@@ -368,6 +399,11 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
             u_limit(u_t, P.m * kG, ut);
             __syncthreads();                                              // #2
             if (s_done[lane]) {
+                if (A.term_state && active) {
+                    float *ts = A.term_state + io * 26 + 13;
+#pragma unroll
+                    for (int i = 0; i < 13; ++i) ts[i] = st[i];
+                }
                 float ic[13], it[13];
                 if (RMODE == 3) {
                     const float *src = A.init + (active ? env : 0) * 26;
@@ -560,6 +596,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_runner_rollout(StepArgs A, Runner
     const int64_t env = tile * kTile + lane;
     const bool active = env < A.n;             // MFMA needs the whole wave: idle lanes carry a nominal env, store nothing
     float *stage = sStage + w * (12 * 64);
+    QS_ASSERT((char *)(stage + 12 * 64) <= lds_raw + sizeof lds_raw);
     Env e;
     if (active) load_env(A.st, tile, lane, e);
     else { nominal_init(e.sc, e.st); for (int i = 0; i < 4; ++i) { e.uc[i] = 0.0f; e.ut[i] = 0.0f; e.qd[i] = i == 0; } e.ls = 0.0f; e.t = 0.0f; }
@@ -572,6 +609,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_runner_rollout(StepArgs A, Runner
 #pragma clang loop unroll(disable)
     for (int64_t t = 0; t < A.T; ++t) {
         const int64_t o = t * A.n + env;
+        QS_ASSERT(!active || (o >= 0 && o < A.T * A.n));
         if (active) store_obs(A.obs, o, obs);                         // mb_obs: the observation the policy acts on
         float head[5];
         if (FAST) mlp_actor_critic_fast(obs, head, lds_raw, stage, lane);
@@ -639,9 +677,11 @@ template <int INTEG, bool PARAMS>
 __global__ __launch_bounds__(kBlock) void k_hover(StepArgs A)
 {
     const int lane = threadIdx.x & (kTile - 1);
-    const int64_t tile = (int64_t)blockIdx.x * (kBlock / kTile) + (threadIdx.x >> 6);
+    const int64_t tile = A.tile0 + (int64_t)blockIdx.x * (kBlock / kTile) + (threadIdx.x >> 6);
     const int64_t env = tile * kTile + lane;
-    if (env >= A.n) return;
+    if (tile >= A.tile_end || env >= A.n) return;
+    const int64_t io = env - A.io_env0;
+    QS_ASSERT(io >= 0 && io < A.io_n);
     const uint64_t k0 = step_counter_begin(A, tile);
     float *b = A.st + tile * (int64_t)(kRecWords * kTile) + lane;
     float s[13], up[4];
@@ -653,7 +693,7 @@ __global__ __launch_bounds__(kBlock) void k_hover(StepArgs A)
     if (PARAMS) P = load_par(A.par, tile, lane);
 #pragma clang loop unroll(disable)
     for (int64_t t = 0; t < A.T; ++t) {
-        const int64_t o = t * A.n + env;
+        const int64_t o = t * A.io_n + io;
         float a[4];
         if (A.actions) {
             const float4 av = reinterpret_cast<const float4 *>(A.actions)[o];
@@ -668,7 +708,7 @@ __global__ __launch_bounds__(kBlock) void k_hover(StepArgs A)
         hover_step<INTEG>(s, up, a, P, A.C.dt, reward, flags);
         const bool done = (flags & FLAG_OVERLIMIT) != 0;
         if (done && A.auto_reset) {
-            if (A.term_obs) for (int i = 0; i < 13; ++i) A.term_obs[env * 13 + i] = s[i];
+            if (A.term_obs) for (int i = 0; i < 13; ++i) A.term_obs[io * 13 + i] = s[i];
             const float *src = A.init + env * 13;
 #pragma unroll
             for (int i = 0; i < 13; ++i) s[i] = src[i];
@@ -1012,6 +1052,11 @@ struct QsEnv {
     size_t stage_bytes = 0;
     char *hpin = nullptr;       // host address of the mirror
     char *hpin_dev = nullptr;   // its device address (kernels of small batches read / write it in place)
+    // env groups (qs_set_groups): contiguous tile ranges stepped on their own streams, optionally by their own launcher threads
+    std::vector<struct QsGroup *> groups;
+    hipEvent_t fork_ev = nullptr;
+    bool main_dirty = true;     // the handle enqueued work on its main stream that the group streams have not been ordered behind
+    bool groups_dirty = false;  // group streams hold work the main stream has not been ordered behind
 };
 
 namespace {
@@ -1023,6 +1068,8 @@ StepArgs make_args(const QsEnv *e)
     A.st = e->st;
     A.par = e->par;
     A.n = e->n;
+    A.tile0 = 0; A.tile_end = e->tiles;
+    A.io_env0 = 0; A.io_n = e->n;
     A.T = 1;
     A.step_idx = 0;
     A.ctr = e->d_ctr;
@@ -1102,42 +1149,198 @@ struct Bounce {
 };
 
 template <int INTEG, bool PARAMS, int RMODE>
-void launch_one(unsigned grid, hipStream_t s, const StepArgs &A)
+void launch_one(hipStream_t s, const StepArgs &A)
 {
     // role-split kernel up to kSplitMaxEnvs envs (few waves per SIMD: the two half-length streams of a tile overlap), the
     // serial kernel above (SIMDs already saturated: the hand-overs only cost).  Both inline the same device functions and
     // the library is built with -ffp-contract=on, so they compute the same bits.  QS_SPLIT=0/1 forces one (A/B runs).
+    // The choice follows the handle's env count, not the launch's: the groups of a handle are in flight together.
     static const int forced = getenv("QS_SPLIT") ? atoi(getenv("QS_SPLIT")) : -1;
     const bool split = forced >= 0 ? forced != 0 : A.n <= kSplitMaxEnvs;
-    if (split) hipLaunchKernelGGL((k_env_split<INTEG, PARAMS, RMODE>), dim3((unsigned)tiles_of(A.n)), dim3(2 * kTile), 0, s, A);
-    else hipLaunchKernelGGL((k_env<INTEG, PARAMS, RMODE>), dim3(grid), dim3(kBlock), 0, s, A);
+    const int64_t tiles = A.tile_end - A.tile0;
+    if (split) hipLaunchKernelGGL((k_env_split<INTEG, PARAMS, RMODE>), dim3((unsigned)tiles), dim3(2 * kTile), 0, s, A);
+    else hipLaunchKernelGGL((k_env<INTEG, PARAMS, RMODE>), dim3((unsigned)((tiles + kBlock / kTile - 1) / (kBlock / kTile))), dim3(kBlock), 0, s, A);
 }
 
 template <int INTEG>
-void launch_integ(unsigned grid, hipStream_t s, const StepArgs &A, bool params, int rmode)
+void launch_integ(hipStream_t s, const StepArgs &A, bool params, int rmode)
 {
-    if (rmode == 3) { if (params) launch_one<INTEG, true, 3>(grid, s, A); else launch_one<INTEG, false, 3>(grid, s, A); }
-    else if (rmode == 2) launch_one<INTEG, true, 2>(grid, s, A);      // per-episode params imply per-env params
-    else if (rmode == 1) { if (params) launch_one<INTEG, true, 1>(grid, s, A); else launch_one<INTEG, false, 1>(grid, s, A); }
-    else { if (params) launch_one<INTEG, true, 0>(grid, s, A); else launch_one<INTEG, false, 0>(grid, s, A); }
+    if (rmode == 3) { if (params) launch_one<INTEG, true, 3>(s, A); else launch_one<INTEG, false, 3>(s, A); }
+    else if (rmode == 2) launch_one<INTEG, true, 2>(s, A);      // per-episode params imply per-env params
+    else if (rmode == 1) { if (params) launch_one<INTEG, true, 1>(s, A); else launch_one<INTEG, false, 1>(s, A); }
+    else { if (params) launch_one<INTEG, true, 0>(s, A); else launch_one<INTEG, false, 0>(s, A); }
 }
 
-int launch_env(QsEnv *e, StepArgs &A)
+// the env kernels of tiles [A.tile0, A.tile_end) on stream s
+int launch_env_on(QsEnv *e, const StepArgs &A, hipStream_t s)
 {
-    const unsigned grid = grid_tiles(e->n);
     if (e->cfg.kind == QS_KIND_HOVERING_V0) {
+        const unsigned grid = (unsigned)((A.tile_end - A.tile0 + kBlock / kTile - 1) / (kBlock / kTile));
         const bool fr = e->cfg.integrator == QS_INTEG_FROZEN, pp = e->per_env_params;
-        if (fr && !pp) hipLaunchKernelGGL((k_hover<0, false>), dim3(grid), dim3(kBlock), 0, e->stream, A);
-        else if (fr) hipLaunchKernelGGL((k_hover<0, true>), dim3(grid), dim3(kBlock), 0, e->stream, A);
-        else if (!pp) hipLaunchKernelGGL((k_hover<1, false>), dim3(grid), dim3(kBlock), 0, e->stream, A);
-        else hipLaunchKernelGGL((k_hover<1, true>), dim3(grid), dim3(kBlock), 0, e->stream, A);
+        if (fr && !pp) hipLaunchKernelGGL((k_hover<0, false>), dim3(grid), dim3(kBlock), 0, s, A);
+        else if (fr) hipLaunchKernelGGL((k_hover<0, true>), dim3(grid), dim3(kBlock), 0, s, A);
+        else if (!pp) hipLaunchKernelGGL((k_hover<1, false>), dim3(grid), dim3(kBlock), 0, s, A);
+        else hipLaunchKernelGGL((k_hover<1, true>), dim3(grid), dim3(kBlock), 0, s, A);
         HIP_TRY(hipGetLastError());
         return QS_OK;
     }
     const int rmode = e->init ? 3 : e->cfg.randomise;   // stored initial states take precedence over `randomise`
-    if (e->cfg.integrator == QS_INTEG_FROZEN) launch_integ<0>(grid, e->stream, A, e->per_env_params, rmode);
-    else launch_integ<1>(grid, e->stream, A, e->per_env_params, rmode);
+    if (e->cfg.integrator == QS_INTEG_FROZEN) launch_integ<0>(s, A, e->per_env_params, rmode);
+    else launch_integ<1>(s, A, e->per_env_params, rmode);
     HIP_TRY(hipGetLastError());
+    return QS_OK;
+}
+
+int launch_env(QsEnv *e, StepArgs &A) { return launch_env_on(e, A, e->stream); }
+
+}  // namespace
+
+// ---- env groups -----------------------------------------------------------------------------------------------------
+// A handle's tiles can be partitioned into G contiguous groups, each stepped on its OWN stream (EnvPool-style: a trainer
+// runs the policy of one group while the others step).  Envs never interact, so a group launch is the ordinary step kernel
+// over a tile range: results are bit-identical to the single launch.  What the groups buy is overlap: at 65 536 envs one
+// step is ~5 us of kernel plus a ~1.8 us dependent-kernel boundary (MI355X_MICROARCH.md, price list, "boundary"); with two
+// chains in flight one group's boundary and wave ramp hide under the other group's compute.  Two launches per step would
+// make ONE host thread the bottleneck (~2.5-3 us per launch), so each group may get its own launcher thread: the API
+// thread posts a launch record into a single-producer ring and returns; the group's thread issues it on the group's stream.
+struct QsGroup {
+    enum { kRing = 64 };
+    enum ReqType { REQ_LAUNCH = 0, REQ_WAIT_EVENT = 1 };
+    struct Req {
+        int type;
+        StepArgs A;
+        hipEvent_t ev;
+    };
+    QsEnv *env = nullptr;
+    int index = 0;
+    int64_t tile0 = 0, tile_end = 0, env0 = 0, env_end = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    hipEvent_t done_ev = nullptr;
+    // launcher thread (optional)
+    bool threaded = false;
+    std::thread th;
+    Req ring[kRing];
+    std::atomic<uint64_t> head{0}, tail{0};     // posted / issued
+    std::atomic<int> stop{0}, sleeping{0}, err{0};
+    std::mutex m;
+    std::condition_variable cv;
+};
+
+namespace {
+
+int group_execute(QsGroup *g, const QsGroup::Req &r)
+{
+    if (r.type == QsGroup::REQ_LAUNCH) return launch_env_on(g->env, r.A, g->stream);
+    HIP_TRY(hipStreamWaitEvent(g->stream, r.ev, 0));
+    return QS_OK;
+}
+
+void group_worker(QsGroup *g)
+{
+    (void)hipSetDevice(g->env->cfg.device);
+    for (;;) {
+        const uint64_t t = g->tail.load(std::memory_order_relaxed);
+        int spins = 0;
+        while (g->head.load(std::memory_order_acquire) == t) {
+            if (g->stop.load(std::memory_order_acquire)) return;
+            if (++spins < 40000) { __builtin_ia32_pause(); continue; }
+            // idle for ~100 us: sleep until the API thread posts again (it checks `sleeping` after publishing)
+            std::unique_lock<std::mutex> lk(g->m);
+            g->sleeping.store(1, std::memory_order_seq_cst);
+            if (g->head.load(std::memory_order_seq_cst) == t && !g->stop.load())
+                g->cv.wait_for(lk, std::chrono::milliseconds(50));
+            g->sleeping.store(0, std::memory_order_seq_cst);
+            spins = 0;
+        }
+        const int rc = group_execute(g, g->ring[t % QsGroup::kRing]);
+        if (rc != QS_OK) { int z = 0; g->err.compare_exchange_strong(z, rc); }
+        g->tail.store(t + 1, std::memory_order_release);
+    }
+}
+
+int group_post(QsGroup *g, const QsGroup::Req &r)
+{
+    if (!g->threaded) return group_execute(g, r);
+    const uint64_t h = g->head.load(std::memory_order_relaxed);
+    while (h - g->tail.load(std::memory_order_acquire) >= QsGroup::kRing) __builtin_ia32_pause();
+    g->ring[h % QsGroup::kRing] = r;
+    g->head.store(h + 1, std::memory_order_seq_cst);
+    if (g->sleeping.load(std::memory_order_seq_cst)) { std::lock_guard<std::mutex> lk(g->m); g->cv.notify_one(); }
+    return QS_OK;
+}
+
+// every posted record has been issued to its stream
+int groups_drain(QsEnv *e)
+{
+    int rc = QS_OK;
+    for (QsGroup *g : e->groups) {
+        if (g->threaded) {
+            const uint64_t h = g->head.load(std::memory_order_relaxed);
+            while (g->tail.load(std::memory_order_acquire) != h) __builtin_ia32_pause();
+        }
+        const int ge = g->err.exchange(0);
+        if (ge != QS_OK && rc == QS_OK) rc = fail(ge, "a group launcher thread reported error %d (group %d)", ge, g->index);
+    }
+    return rc;
+}
+
+// group streams wait for everything enqueued so far on the main stream
+int groups_fork(QsEnv *e)
+{
+    if (e->groups.empty()) return QS_OK;
+    HIP_TRY(hipEventRecord(e->fork_ev, e->stream));
+    for (QsGroup *g : e->groups) {
+        QsGroup::Req r;
+        r.type = QsGroup::REQ_WAIT_EVENT;
+        r.ev = e->fork_ev;
+        int rc = group_post(g, r);
+        if (rc) return rc;
+    }
+    // a re-record of fork_ev must not overtake a wait that has not been issued yet
+    int rc = groups_drain(e);
+    e->main_dirty = false;
+    return rc;
+}
+
+// the main stream waits for everything enqueued so far on the group streams
+int groups_join(QsEnv *e)
+{
+    if (e->groups.empty()) return QS_OK;
+    int rc = groups_drain(e);
+    if (rc) return rc;
+    for (QsGroup *g : e->groups) {
+        HIP_TRY(hipEventRecord(g->done_ev, g->stream));
+        HIP_TRY(hipStreamWaitEvent(e->stream, g->done_ev, 0));
+    }
+    e->groups_dirty = false;
+    return QS_OK;
+}
+
+void groups_destroy(QsEnv *e)
+{
+    for (QsGroup *g : e->groups) {
+        if (g->threaded) {
+            g->stop.store(1, std::memory_order_release);
+            { std::lock_guard<std::mutex> lk(g->m); g->cv.notify_one(); }
+            if (g->th.joinable()) g->th.join();
+        }
+        if (g->stream) (void)hipStreamSynchronize(g->stream);
+        if (g->done_ev) (void)hipEventDestroy(g->done_ev);
+        if (g->own_stream && g->stream) (void)hipStreamDestroy(g->stream);
+        delete g;
+    }
+    e->groups.clear();
+    if (e->fork_ev) { (void)hipEventDestroy(e->fork_ev); e->fork_ev = nullptr; }
+    e->groups_dirty = false;
+    e->main_dirty = true;
+}
+
+// entry points that use the main stream: order it behind pending group work first, and mark it dirty for the groups
+int main_stream_entry(QsEnv *e)
+{
+    if (e->groups_dirty) { int rc = groups_join(e); if (rc) return rc; }
+    e->main_dirty = true;
     return QS_OK;
 }
 
@@ -1161,10 +1364,14 @@ int do_reset(QsEnv *e, const uint8_t *d_mask, float *d_obs, int init_all)
     return QS_OK;
 }
 
-#define CHECK_ENV(e)                                                   \
+// CHECK_ENV_RAW: handle + device; CHECK_ENV: + this call uses the main stream (joins pending group work first)
+#define CHECK_ENV_RAW(e)                                               \
     if (!(e)) return fail(QS_ERR_INVALID, "%s: null handle", __func__); \
     DeviceGuard guard_((e)->cfg.device);                               \
     if (!guard_.ok) return fail(QS_ERR_HIP, "%s: hipSetDevice(%d) failed", __func__, (e)->cfg.device)
+#define CHECK_ENV(e)                                                   \
+    CHECK_ENV_RAW(e);                                                  \
+    if (!(e)->groups.empty()) { int rcj_ = main_stream_entry(e); if (rcj_) return rcj_; }
 
 }  // namespace
 
@@ -1280,6 +1487,7 @@ int qs_destroy(QsEnv *e)
 {
     if (!e) return QS_OK;
     DeviceGuard guard(e->cfg.device);
+    groups_destroy(e);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->st) (void)hipFree(e->st);
     if (e->par) (void)hipFree(e->par);
@@ -1377,20 +1585,24 @@ int qs_reset(QsEnv *e, const uint8_t *mask, float *obs_out)
     return QS_OK;
 }
 
-int qs_step(QsEnv *e, const float *actions, float *obs, float *reward, uint8_t *done, uint8_t *flags, float *terminal_obs)
+int qs_step_ex(QsEnv *e, const float *actions, float *obs, float *reward, uint8_t *done, uint8_t *flags, float *terminal_obs,
+               float *terminal_state)
 {
     CHECK_ENV(e);
     if (!actions || !obs || !reward || !done) return fail(QS_ERR_INVALID, "qs_step: actions, obs, reward and done are required");
+    if (terminal_state && e->cfg.kind == QS_KIND_HOVERING_V0)
+        return fail(QS_ERR_INVALID, "qs_step_ex: hovering-v0 has no terminal_state (its terminal observation IS the state)");
     const int64_t n = e->n;
     StepArgs A = make_args(e);
     int r;
     if (e->cfg.io_space == QS_IO_DEVICE) {
         A.actions = actions; A.obs = obs; A.reward = reward; A.done = done; A.flags = flags; A.term_obs = terminal_obs;
+        A.term_state = terminal_state;
         r = launch_env(e, A);
         if (r) return r;
     } else {
         const int64_t od = e->obs_dim;
-        const size_t need = (size_t)n * (4 * 4 + od * 4 + 4 + 1 + 1 + od * 4) + 4096;
+        const size_t need = (size_t)n * (4 * 4 + od * 4 + 4 + 1 + 1 + od * 4 + 26 * 4) + 4096;
         r = ensure_stage(e, need);
         if (r) return r;
         Bounce B(e, need);
@@ -1399,6 +1611,7 @@ int qs_step(QsEnv *e, const float *actions, float *obs, float *reward, uint8_t *
         float *d_obs = B.take<float>(n * od), *d_rew = B.take<float>(n);
         uint8_t *d_done = B.take<uint8_t>(n), *d_flags = B.take<uint8_t>(n);
         float *d_term = B.take<float>(n * od);
+        float *d_tst = B.take<float>(n * 26);
         memcpy(B.host(d_act), actions, n * 4 * sizeof(float));
         if ((r = B.push())) return r;
         if (terminal_obs) {
@@ -1406,8 +1619,13 @@ int qs_step(QsEnv *e, const float *actions, float *obs, float *reward, uint8_t *
             memcpy(B.host(d_term), terminal_obs, n * od * sizeof(float));
             if (!B.direct) HIP_TRY(hipMemcpyAsync(d_term, B.host(d_term), n * od * sizeof(float), hipMemcpyHostToDevice, e->stream));
         }
+        if (terminal_state) {
+            memcpy(B.host(d_tst), terminal_state, n * 26 * sizeof(float));
+            if (!B.direct) HIP_TRY(hipMemcpyAsync(d_tst, B.host(d_tst), n * 26 * sizeof(float), hipMemcpyHostToDevice, e->stream));
+        }
         A.actions = d_act; A.obs = d_obs; A.reward = d_rew; A.done = d_done; A.flags = d_flags;
         A.term_obs = terminal_obs ? d_term : nullptr;
+        A.term_state = terminal_state ? d_tst : nullptr;
         r = launch_env(e, A);
         if (r) return r;
         if ((r = B.pull())) return r;
@@ -1416,6 +1634,141 @@ int qs_step(QsEnv *e, const float *actions, float *obs, float *reward, uint8_t *
         memcpy(done, B.host(d_done), n);
         if (flags) memcpy(flags, B.host(d_flags), n);
         if (terminal_obs) memcpy(terminal_obs, B.host(d_term), n * od * sizeof(float));
+        if (terminal_state) memcpy(terminal_state, B.host(d_tst), n * 26 * sizeof(float));
+    }
+    return QS_OK;
+}
+
+int qs_step(QsEnv *e, const float *actions, float *obs, float *reward, uint8_t *done, uint8_t *flags, float *terminal_obs)
+{
+    return qs_step_ex(e, actions, obs, reward, done, flags, terminal_obs, nullptr);
+}
+
+// ---- env groups: see the QsGroup comment above ---------------------------------------------------------------------
+int qs_set_groups(QsEnv *e, int32_t groups, int32_t launcher_threads)
+{
+    CHECK_ENV(e);                                     // joins and thereby retires any previous grouping's work
+    if (groups < 0 || groups > 64) return fail(QS_ERR_INVALID, "qs_set_groups: groups must be 0..64");
+    if (e->cfg.io_space != QS_IO_DEVICE && groups > 1) return fail(QS_ERR_INVALID, "qs_set_groups: device buffers only");
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    groups_destroy(e);
+    if (groups <= 1) return QS_OK;
+    if (groups > e->tiles) groups = (int32_t)e->tiles;
+    HIP_TRY(hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming));
+    const int64_t base = e->tiles / groups, rem = e->tiles % groups;
+    int64_t t0 = 0;
+    for (int32_t i = 0; i < groups; ++i) {
+        QsGroup *g = new (std::nothrow) QsGroup();
+        if (!g) return fail(QS_ERR_NOMEM, "qs_set_groups: out of host memory");
+        e->groups.push_back(g);
+        g->env = e;
+        g->index = i;
+        g->tile0 = t0;
+        g->tile_end = t0 + base + (i < rem ? 1 : 0);
+        t0 = g->tile_end;
+        g->env0 = g->tile0 * kTile;
+        g->env_end = g->tile_end * kTile < e->n ? g->tile_end * kTile : e->n;
+        hipError_t he = hipStreamCreateWithFlags(&g->stream, hipStreamNonBlocking);
+        if (he == hipSuccess) { g->own_stream = true; he = hipEventCreateWithFlags(&g->done_ev, hipEventDisableTiming); }
+        if (he != hipSuccess) { groups_destroy(e); return fail(QS_ERR_HIP, "qs_set_groups: %s", hipGetErrorString(he)); }
+    }
+    for (QsGroup *g : e->groups) {
+        g->threaded = launcher_threads != 0;
+        if (g->threaded) g->th = std::thread(group_worker, g);
+    }
+    e->main_dirty = true;
+    return QS_OK;
+}
+
+int qs_group_count(QsEnv *e, int32_t *groups)
+{
+    if (!e || !groups) return fail(QS_ERR_INVALID, "qs_group_count: null argument");
+    *groups = e->groups.empty() ? 1 : (int32_t)e->groups.size();
+    return QS_OK;
+}
+
+int qs_group_range(QsEnv *e, int32_t g, int64_t *env_begin, int64_t *env_end)
+{
+    if (!e || !env_begin || !env_end) return fail(QS_ERR_INVALID, "qs_group_range: null argument");
+    if (e->groups.empty()) {
+        if (g != 0) return fail(QS_ERR_INVALID, "qs_group_range: group %d out of range", g);
+        *env_begin = 0; *env_end = e->n;
+        return QS_OK;
+    }
+    if (g < 0 || g >= (int32_t)e->groups.size()) return fail(QS_ERR_INVALID, "qs_group_range: group %d out of range", g);
+    *env_begin = e->groups[g]->env0; *env_end = e->groups[g]->env_end;
+    return QS_OK;
+}
+
+int qs_group_stream(QsEnv *e, int32_t g, void **hip_stream)
+{
+    if (!e || !hip_stream) return fail(QS_ERR_INVALID, "qs_group_stream: null argument");
+    if (g < 0 || g >= (int32_t)e->groups.size()) return fail(QS_ERR_INVALID, "qs_group_stream: group %d out of range", g);
+    *hip_stream = (void *)e->groups[g]->stream;
+    return QS_OK;
+}
+
+int qs_group_set_stream(QsEnv *e, int32_t g, void *hip_stream)
+{
+    CHECK_ENV(e);                                     // joins: nothing of this group is pending on its old stream afterwards
+    if (g < 0 || g >= (int32_t)e->groups.size()) return fail(QS_ERR_INVALID, "qs_group_set_stream: group %d out of range", g);
+    QsGroup *G = e->groups[g];
+    HIP_TRY(hipStreamSynchronize(G->stream));
+    if (G->own_stream) { HIP_TRY(hipStreamDestroy(G->stream)); G->own_stream = false; }
+    G->stream = (hipStream_t)hip_stream;
+    return QS_OK;
+}
+
+int qs_groups_fork(QsEnv *e)
+{
+    CHECK_ENV_RAW(e);
+    return groups_fork(e);
+}
+
+int qs_groups_join(QsEnv *e)
+{
+    CHECK_ENV_RAW(e);
+    return groups_join(e);
+}
+
+static int step_group_post(QsEnv *e, QsGroup *G, const float *actions, float *obs, float *reward, uint8_t *done, uint8_t *flags,
+                           float *terminal_obs, float *terminal_state, bool group_local)
+{
+    QsGroup::Req r;
+    r.type = QsGroup::REQ_LAUNCH;
+    r.ev = nullptr;
+    r.A = make_args(e);
+    r.A.tile0 = G->tile0; r.A.tile_end = G->tile_end;
+    if (group_local) { r.A.io_env0 = G->env0; r.A.io_n = G->env_end - G->env0; }
+    r.A.actions = actions; r.A.obs = obs; r.A.reward = reward; r.A.done = done; r.A.flags = flags;
+    r.A.term_obs = terminal_obs; r.A.term_state = terminal_state;
+    return group_post(G, r);
+}
+
+int qs_step_group(QsEnv *e, int32_t g, const float *actions, float *obs, float *reward, uint8_t *done, uint8_t *flags,
+                  float *terminal_obs, float *terminal_state)
+{
+    CHECK_ENV_RAW(e);
+    if (g < 0 || g >= (int32_t)e->groups.size()) return fail(QS_ERR_INVALID, "qs_step_group: group %d out of range (qs_set_groups first)", g);
+    if (!actions || !obs || !reward || !done) return fail(QS_ERR_INVALID, "qs_step_group: actions, obs, reward and done are required");
+    if (terminal_state && e->cfg.kind == QS_KIND_HOVERING_V0) return fail(QS_ERR_INVALID, "qs_step_group: hovering-v0 has no terminal_state");
+    if (e->main_dirty) { int rc = groups_fork(e); if (rc) return rc; }
+    e->groups_dirty = true;
+    return step_group_post(e, e->groups[g], actions, obs, reward, done, flags, terminal_obs, terminal_state, true);
+}
+
+int qs_step_groups(QsEnv *e, const float *actions, float *obs, float *reward, uint8_t *done, uint8_t *flags, float *terminal_obs,
+                   float *terminal_state)
+{
+    CHECK_ENV_RAW(e);
+    if (e->groups.empty()) return qs_step_ex(e, actions, obs, reward, done, flags, terminal_obs, terminal_state);
+    if (!actions || !obs || !reward || !done) return fail(QS_ERR_INVALID, "qs_step_groups: actions, obs, reward and done are required");
+    if (terminal_state && e->cfg.kind == QS_KIND_HOVERING_V0) return fail(QS_ERR_INVALID, "qs_step_groups: hovering-v0 has no terminal_state");
+    if (e->main_dirty) { int rc = groups_fork(e); if (rc) return rc; }
+    e->groups_dirty = true;
+    for (QsGroup *G : e->groups) {
+        int rc = step_group_post(e, G, actions, obs, reward, done, flags, terminal_obs, terminal_state, false);
+        if (rc) return rc;
     }
     return QS_OK;
 }
@@ -1698,6 +2051,57 @@ int qs_swap_and_flatten(QsEnv *e, int64_t T, int64_t n, int64_t d, const float *
         case 13: hipLaunchKernelGGL(k_swap_flatten<13>, grid, dim3(256), 0, e->stream, in, out, T, n); break;
         default: return fail(QS_ERR_INVALID, "qs_swap_and_flatten: row width %lld not supported (1, 4, 12, 13)", (long long)d);
     }
+    HIP_TRY(hipGetLastError());
+    return QS_OK;
+}
+
+int qs_swap_and_flatten_u8(QsEnv *e, int64_t T, int64_t n, const uint8_t *in, uint8_t *out)
+{
+    CHECK_ENV(e);
+    if (T < 1 || n < 1 || !in || !out) return fail(QS_ERR_INVALID, "qs_swap_and_flatten_u8: bad arguments");
+    if (e->cfg.io_space != QS_IO_DEVICE) return fail(QS_ERR_INVALID, "qs_swap_and_flatten_u8: device buffers only");
+    dim3 grid((unsigned)((n + 31) / 32), (unsigned)((T + 31) / 32));
+    hipLaunchKernelGGL((k_swap_flatten<1, uint8_t>), grid, dim3(256), 0, e->stream, in, out, T, n);
+    HIP_TRY(hipGetLastError());
+    return QS_OK;
+}
+
+int qs_gae_flatten(QsEnv *e, int64_t T, int64_t n, const float *rewards, const float *values, const float *neglogp,
+                   const uint8_t *dones, const float *last_values, const uint8_t *last_dones, float gamma, float lam,
+                   float *flat_returns, float *flat_values, float *flat_neglogp, float *flat_rewards, uint8_t *flat_masks,
+                   float *advs, float *returns)
+{
+    CHECK_ENV(e);
+    if (T < 1 || n < 1 || !rewards || !values || !dones || !last_values || !last_dones || !flat_returns || !flat_values ||
+        !flat_rewards || !flat_masks)
+        return fail(QS_ERR_INVALID, "qs_gae_flatten: bad arguments");
+    if ((neglogp == nullptr) != (flat_neglogp == nullptr)) return fail(QS_ERR_INVALID, "qs_gae_flatten: neglogp and flat_neglogp go together");
+    if ((advs == nullptr) != (returns == nullptr)) return fail(QS_ERR_INVALID, "qs_gae_flatten: advs and returns go together");
+    if (e->cfg.io_space != QS_IO_DEVICE) return fail(QS_ERR_INVALID, "qs_gae_flatten: device buffers only");
+    GaeFlatArgs G;
+    G.rewards = rewards; G.values = values; G.neglogp = neglogp; G.last_values = last_values;
+    G.dones = dones; G.last_dones = last_dones;
+    G.f_returns = flat_returns; G.f_values = flat_values; G.f_neglogp = flat_neglogp; G.f_rewards = flat_rewards;
+    G.f_masks = flat_masks; G.advs = advs; G.returns = returns;
+    G.T = T; G.N = n; G.gamma = gamma; G.lam = lam;
+    hipLaunchKernelGGL(k_gae_flatten, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, G);
+    HIP_TRY(hipGetLastError());
+    return QS_OK;
+}
+
+int qs_episode_stats(QsEnv *e, int64_t T, int64_t n, const float *rewards, const uint8_t *dones, const uint8_t *last_dones,
+                     float *ep_ret, int32_t *ep_len, uint64_t *count, int64_t cap, int64_t *out_key, float *out_ret, int32_t *out_len)
+{
+    CHECK_ENV(e);
+    if (T < 1 || n < 1 || cap < 0 || !rewards || !dones || !last_dones || !ep_ret || !ep_len || !count || (cap > 0 && (!out_key || !out_ret || !out_len)))
+        return fail(QS_ERR_INVALID, "qs_episode_stats: bad arguments");
+    if (e->cfg.io_space != QS_IO_DEVICE) return fail(QS_ERR_INVALID, "qs_episode_stats: device buffers only");
+    EpisodeArgs E;
+    E.rewards = rewards; E.dones = dones; E.last_dones = last_dones; E.ep_ret = ep_ret; E.ep_len = ep_len;
+    E.count = (unsigned long long *)count; E.out_key = out_key; E.out_ret = out_ret; E.out_len = out_len;
+    E.T = T; E.N = n; E.cap = cap;
+    HIP_TRY(hipMemsetAsync(count, 0, sizeof(uint64_t), e->stream));
+    hipLaunchKernelGGL(k_episode_stats, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, e->stream, E);
     HIP_TRY(hipGetLastError());
     return QS_OK;
 }

@@ -5,6 +5,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef QS_ASSERT
+#define QS_ASSERT(c) ((void)0)
+#endif
+
 namespace qs {
 
 constexpr int kGaeChunk = 64;   // steps per chunk of the two-pass scan
@@ -89,6 +93,7 @@ __global__ __launch_bounds__(256) void k_gae_serial(GaeArgs G)
 #pragma unroll
         for (int j = 0; j < kGaeGroup; ++j) {
             const int64_t o = (t - j) * G.N + i;
+            QS_ASSERT(o >= 0 && o < G.T * G.N);
             r[j] = G.rewards[o]; v[j] = G.values[o]; d[j] = G.dones[o];
         }
 #pragma unroll
@@ -117,14 +122,15 @@ __global__ __launch_bounds__(256) void k_gae_serial(GaeArgs G)
 // swap_and_flatten (ppo2.py:531-539): in [T][N][D] -> out [N][T][D].  32 x 32 tile of D-float rows staged in
 // LDS so that both the global reads (rows of consecutive envs) and writes (rows of consecutive steps) are
 // contiguous runs of 32*D floats.
-template <int D>
-__global__ __launch_bounds__(256) void k_swap_flatten(const float *__restrict__ in, float *__restrict__ out, int64_t T, int64_t N)
+template <int D, typename E = float>
+__global__ __launch_bounds__(256) void k_swap_flatten(const E *__restrict__ in, E *__restrict__ out, int64_t T, int64_t N)
 {
-    __shared__ float tile[32][32 * D + 1];
+    __shared__ E tile[32][32 * D + 1];
     const int64_t i0 = (int64_t)blockIdx.x * 32, t0 = (int64_t)blockIdx.y * 32;
     for (int idx = threadIdx.x; idx < 32 * 32 * D; idx += 256) {
         const int tt = idx / (32 * D), r = idx - tt * (32 * D);      // r = ii*D + d
         const int64_t t = t0 + tt, i = i0 + r / D;
+        QS_ASSERT(!(t < T && i < N) || (t * N + i0) * D + r < T * N * D);
         if (t < T && i < N) tile[tt][r] = in[(t * N + i0) * D + r];
     }
     __syncthreads();
@@ -132,6 +138,7 @@ __global__ __launch_bounds__(256) void k_swap_flatten(const float *__restrict__ 
         const int ii = idx / (32 * D), r = idx - ii * (32 * D);      // r = tt*D + d
         const int tt = r / D, d = r - tt * D;
         const int64_t i = i0 + ii, t = t0 + tt;
+        QS_ASSERT(!(t < T && i < N) || (i * T + t0) * D + r < T * N * D);
         if (t < T && i < N) out[(i * T + t0) * D + r] = tile[tt][ii * D + d];
     }
 }
@@ -146,14 +153,165 @@ __global__ __launch_bounds__(256) void k_swap_flatten_v4(const float4 *__restric
     const int ni = (int)min((int64_t)32, N - i0), nt = (int)min((int64_t)32, T - t0);
     for (int idx = threadIdx.x; idx < 32 * 32 * D4; idx += 256) {
         const int tt = idx / (32 * D4), r = idx - tt * (32 * D4);      // r = ii*D4 + q
+        QS_ASSERT(!(tt < nt && r < ni * D4) || ((t0 + tt) * N + i0) * D4 + r < T * N * D4);
         if (tt < nt && r < ni * D4) tile[tt][r] = in[((t0 + tt) * N + i0) * D4 + r];
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < 32 * 32 * D4; idx += 256) {
         const int ii = idx / (32 * D4), r = idx - ii * (32 * D4);      // r = tt*D4 + q
         const int tt = r / D4, q = r - tt * D4;
+        QS_ASSERT(!(ii < ni && tt < nt) || ((i0 + ii) * T + t0) * D4 + r < T * N * D4);
         if (ii < ni && tt < nt) out[((i0 + ii) * T + t0) * D4 + r] = tile[tt][ii * D4 + q];
     }
+}
+
+
+// ---- GAE + the env-major flatten of everything that is one scalar per (t, env), in ONE pass -----------------------------
+// Runner.run (rl_baselines/ppo2/ppo2.py:507-523) computes mb_returns from (rewards, values, dones) and then hands
+// swap_and_flatten(mb_returns), (mb_dones), (mb_values), (mb_neglogpacs), (true_reward) to the trainer.  The reverse scan
+// already holds r, v, d of 16 steps per lane in registers, so it can emit all of them env-major itself: each lane writes
+// 64 contiguous bytes per array and group (four 16-B stores) instead of re-reading [T,N] arrays in five more launches.
+// Reads 13 B, writes 17 B (+ 8 B for the optional time-major advs / returns) per (t, env).
+struct GaeFlatArgs {
+    const float *rewards, *values, *neglogp, *last_values;   // [T,N] x3 (neglogp nullable), [N]
+    const uint8_t *dones, *last_dones;                        // [T,N], [N]
+    float *f_returns, *f_values, *f_neglogp, *f_rewards;      // [N,T] env-major (f_neglogp nullable with neglogp)
+    uint8_t *f_masks;                                         // [N,T] env-major mb_dones (0/1)
+    float *advs, *returns;                                    // nullable [T,N] time-major (what qs_gae returns)
+    int64_t T, N;
+    float gamma, lam;
+};
+
+__global__ __launch_bounds__(256) void k_gae_flatten(GaeFlatArgs G)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= G.N) return;
+    float A = 0.0f;
+    float nextv = G.last_values[i];
+    float nonterm = G.last_dones[i] ? 0.0f : 1.0f;
+    int64_t t = G.T - 1;
+    const float gl = G.gamma * G.lam;
+    const bool vec = (G.T & 3) == 0;                         // env-major rows are 16-B aligned
+    const int64_t row = i * G.T;
+    for (; t >= kGaeGroup - 1; t -= kGaeGroup) {
+        float r[kGaeGroup], v[kGaeGroup], nl[kGaeGroup], ret[kGaeGroup];
+        uint8_t d[kGaeGroup];
+#pragma unroll
+        for (int j = 0; j < kGaeGroup; ++j) {
+            const int64_t o = (t - j) * G.N + i;
+            QS_ASSERT(o >= 0 && o < G.T * G.N);
+            r[j] = G.rewards[o]; v[j] = G.values[o]; d[j] = G.dones[o];
+            nl[j] = G.neglogp ? G.neglogp[o] : 0.0f;
+        }
+#pragma unroll
+        for (int j = 0; j < kGaeGroup; ++j) {
+            const float delta = r[j] + (G.gamma * nextv) * nonterm - v[j];
+            A = fmaf(gl * nonterm, A, delta);
+            ret[j] = A + v[j];
+            if (G.advs) { const int64_t o = (t - j) * G.N + i; G.advs[o] = A; G.returns[o] = ret[j]; }
+            nextv = v[j];
+            nonterm = d[j] ? 0.0f : 1.0f;
+        }
+        // element j belongs to step t - j: the group covers steps [t-15, t] -> env-major offsets row + t-15 .. row + t
+        const int64_t b = row + t - (kGaeGroup - 1);
+        QS_ASSERT(b >= 0 && b + kGaeGroup <= G.N * G.T);
+        if (vec) {
+#pragma unroll
+            for (int q = 0; q < kGaeGroup / 4; ++q) {
+                const int j0 = kGaeGroup - 1 - 4 * q;         // step b + 4q is element j0
+                reinterpret_cast<float4 *>(G.f_returns + b)[q] = make_float4(ret[j0], ret[j0 - 1], ret[j0 - 2], ret[j0 - 3]);
+                reinterpret_cast<float4 *>(G.f_values + b)[q] = make_float4(v[j0], v[j0 - 1], v[j0 - 2], v[j0 - 3]);
+                reinterpret_cast<float4 *>(G.f_rewards + b)[q] = make_float4(r[j0], r[j0 - 1], r[j0 - 2], r[j0 - 3]);
+                if (G.f_neglogp) reinterpret_cast<float4 *>(G.f_neglogp + b)[q] = make_float4(nl[j0], nl[j0 - 1], nl[j0 - 2], nl[j0 - 3]);
+                reinterpret_cast<uchar4 *>(G.f_masks + b)[q] = make_uchar4(d[j0] ? 1 : 0, d[j0 - 1] ? 1 : 0, d[j0 - 2] ? 1 : 0, d[j0 - 3] ? 1 : 0);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < kGaeGroup; ++j) {
+                const int64_t o = row + t - j;
+                G.f_returns[o] = ret[j]; G.f_values[o] = v[j]; G.f_rewards[o] = r[j];
+                if (G.f_neglogp) G.f_neglogp[o] = nl[j];
+                G.f_masks[o] = d[j] ? 1 : 0;
+            }
+        }
+    }
+    for (; t >= 0; --t) {
+        const int64_t o = t * G.N + i;
+        const float r = G.rewards[o], v = G.values[o];
+        const uint8_t d = G.dones[o];
+        const float delta = r + (G.gamma * nextv) * nonterm - v;
+        A = fmaf(gl * nonterm, A, delta);
+        if (G.advs) { G.advs[o] = A; G.returns[o] = A + v; }
+        const int64_t f = row + t;
+        G.f_returns[f] = A + v; G.f_values[f] = v; G.f_rewards[f] = r;
+        if (G.f_neglogp) G.f_neglogp[f] = G.neglogp[o];
+        G.f_masks[f] = d ? 1 : 0;
+        nextv = v;
+        nonterm = d ? 0.0f : 1.0f;
+    }
+}
+
+// ---- episode accounting of one roll-out (what the Monitor wrapper of run_docking_ppo2.py:19-35 reports through
+// info['episode'] and Runner._run collects into ep_infos, ppo2.py:486-489): for every episode that ENDS inside the roll-out
+// its return and length.  One lane per env walks t forward carrying (return, length) across roll-outs in ep_ret / ep_len.
+// done-after-step-t = dones[t+1] (t < T-1) / last_dones (t = T-1): mb_dones holds the flags BEFORE each step (:479).
+// Output is a compact list (key = t*N + env, return, length) in wave-segment order: pass 1 counts the wave's episodes,
+// ONE atomic add per wave reserves its segment, pass 2 fills it ordered by (t, lane).  Sorting by key gives the
+// reference's (step, env) order.
+struct EpisodeArgs {
+    const float *rewards;              // [T,N]
+    const uint8_t *dones, *last_dones; // [T,N] flags before each step, [N] flags after the last one
+    float *ep_ret;                     // [N] in/out: return of the unfinished episode
+    int32_t *ep_len;                   // [N] in/out
+    unsigned long long *count;         // device counter (zeroed by the caller): episodes appended so far
+    int64_t *out_key;                  // [cap]
+    float *out_ret;                    // [cap]
+    int32_t *out_len;                  // [cap]
+    int64_t T, N, cap;
+};
+
+__device__ __forceinline__ bool ep_done_after(const EpisodeArgs &E, int64_t t, int64_t i)
+{
+    return (t + 1 < E.T ? E.dones[(t + 1) * E.N + i] : E.last_dones[i]) != 0;
+}
+
+__global__ __launch_bounds__(256) void k_episode_stats(EpisodeArgs E)
+{
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const bool active = i < E.N;
+    const int64_t ii = active ? i : 0;
+    const int lane = threadIdx.x & 63;
+    // pass 1: episodes ending in this lane's env, then in this wave
+    unsigned mine = 0;
+    for (int64_t t = 0; t < E.T; ++t) mine += (active && ep_done_after(E, t, ii)) ? 1u : 0u;
+    unsigned total = mine;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
+    unsigned long long base = 0;
+    if (lane == 0 && total) base = atomicAdd(E.count, (unsigned long long)total);
+    base = __shfl(base, 0, 64);
+    // pass 2: the running sums; a step's finished episodes go to consecutive slots in lane order
+    float ret = active ? E.ep_ret[ii] : 0.0f;
+    int32_t len = active ? E.ep_len[ii] : 0;
+    unsigned long long next = base;
+    for (int64_t t = 0; t < E.T; ++t) {
+        const float r = active ? E.rewards[t * E.N + ii] : 0.0f;
+        ret += r;
+        len += 1;
+        const bool d = active && ep_done_after(E, t, ii);
+        const unsigned long long bal = __ballot(d);
+        if (bal) {
+            if (d) {
+                const unsigned long long slot = next + (unsigned long long)__popcll(bal & ((1ull << lane) - 1ull));
+                QS_ASSERT(slot < base + total);
+                if ((int64_t)slot < E.cap) { E.out_key[slot] = t * E.N + ii; E.out_ret[slot] = ret; E.out_len[slot] = len; }
+                ret = 0.0f;
+                len = 0;
+            }
+            next += (unsigned long long)__popcll(bal);
+        }
+    }
+    if (active) { E.ep_ret[ii] = ret; E.ep_len[ii] = len; }
 }
 
 }  // namespace qs

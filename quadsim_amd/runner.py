@@ -14,7 +14,7 @@ import math
 import numpy as np
 
 from . import _lib
-from .rollout_buffer import compute_gae, swap_and_flatten
+from .rollout_buffer import EpisodeTracker, compute_gae, gae_and_flatten, swap_and_flatten
 
 
 class ActorCriticPolicy:
@@ -194,35 +194,35 @@ class Runner:
         self.fused = can_fuse if fused is None else bool(fused)
         self.collect_ep_infos = collect_ep_infos       # build the reference's list of {'r', 'l'} dicts on the host
         self.track_episodes = track_episodes           # keep episode returns / lengths at all (device tensors
-        self.last_ep_returns = self.last_ep_lengths = None   # last_ep_returns / last_ep_lengths after each run)
+        #                                                last_ep_returns / last_ep_lengths after each run)
         self.obs = env.reset()
         self.states = model.initial_state
         self.dones = torch.zeros((env.num_envs,), dtype=torch.uint8, device=env.device)
-        self._ep_ret = torch.zeros((env.num_envs,), dtype=torch.float32, device=env.device)
-        self._ep_len = torch.zeros((env.num_envs,), dtype=torch.int64, device=env.device)
+        self._episodes = EpisodeTracker(env) if track_episodes else None
         self.num_timesteps = 0
 
-    def _episode_infos(self, rewards, done_after):
-        """returns / lengths of the episodes that ended inside this roll-out (segmented sums over [T,N], no host loop)"""
-        t = self.torch
-        T, n = rewards.shape
-        csum = rewards.cumsum(0)
-        idx = t.arange(T, device=rewards.device).view(T, 1).expand(T, n)
-        last = t.where(done_after, idx, t.full_like(idx, -1)).cummax(0).values       # latest done at or before t
-        prev = t.cat([t.full((1, n), -1, dtype=idx.dtype, device=idx.device), last[:-1]], 0)
-        base = t.where(prev >= 0, csum.gather(0, prev.clamp(min=0)), -self._ep_ret.view(1, n).expand(T, n))
-        ret = csum - base
-        length = t.where(prev >= 0, idx - prev, idx + 1 + self._ep_len.view(1, n))
-        # carry the unfinished episodes into the next run
-        lastd = last[-1]
-        tail = csum[-1] - t.where(lastd >= 0, csum.gather(0, lastd.clamp(min=0).view(1, n))[0], -self._ep_ret)
-        self._ep_ret = tail
-        self._ep_len = t.where(lastd >= 0, (T - 1) - lastd, self._ep_len + T)
-        self.last_ep_returns, self.last_ep_lengths = ret[done_after], length[done_after]     # device tensors, (t, env) order
+    @property
+    def last_ep_returns(self):
+        """returns of the episodes that ended in the last run(), (step, env) order (device tensor)"""
+        return self._episodes.results()[0] if self._episodes is not None and self._episodes._bufs is not None else None
+
+    @property
+    def last_ep_lengths(self):
+        return self._episodes.results()[1] if self._episodes is not None and self._episodes._bufs is not None else None
+
+    @property
+    def last_ep_count(self):
+        return self._episodes.count if self._episodes is not None and self._episodes._bufs is not None else 0
+
+    def _episode_infos(self, rewards, dones, last_dones):
+        """returns / lengths of the episodes that ended inside this roll-out: ONE kernel (qs_episode_stats), no [T,N]
+        temporaries; the reference's list of dicts is only built on request"""
+        self._episodes.update(rewards, dones, last_dones)
         if not self.collect_ep_infos:
             return []
-        r = self.last_ep_returns.cpu().numpy()
-        l_ = self.last_ep_lengths.cpu().numpy()
+        ret, ln, _ = self._episodes.results(ordered=True)
+        r = ret.cpu().numpy()
+        l_ = ln.cpu().numpy()
         return [{"r": float(a), "l": int(b)} for a, b in zip(r, l_)]
 
     def _stepwise_rollout(self, noise=None):
@@ -255,16 +255,15 @@ class Runner:
         else:
             ro = self._stepwise_rollout(noise)
         self.num_timesteps += T * env.num_envs
-        mb_advs, mb_returns = compute_gae(env, ro["rewards"], ro["values"], ro["dones"], ro["last_values"],
-                                          ro["last_dones"], self.gamma, self.lam)          # ppo2.py:507-520
+        # ppo2.py:507-523 in one pass: GAE + the env-major flatten of returns / dones / values / neglogp / rewards
+        gf = gae_and_flatten(env, ro["rewards"], ro["values"], ro["neglogp"], ro["dones"], ro["last_values"],
+                             ro["last_dones"], self.gamma, self.lam)
         ep_infos = []
         if self.track_episodes:
-            done_after = t.cat([ro["dones"][1:], ro["last_dones"].view(1, -1)], 0).bool()
-            ep_infos = self._episode_infos(ro["rewards"], done_after)
+            ep_infos = self._episode_infos(ro["rewards"], ro["dones"], ro["last_dones"])
         self.obs, self.dones = ro["last_obs"], ro["last_dones"]
-        flat = lambda x: swap_and_flatten(env, x)                                          # noqa: E731  ppo2.py:522-523
-        out = (flat(ro["obs"]), flat(mb_returns), flat(ro["dones"]).bool(), flat(ro["actions"]), flat(ro["values"]),
-               flat(ro["neglogp"]), mb_states, ep_infos, flat(ro["rewards"]))
+        out = (swap_and_flatten(env, ro["obs"]), gf["returns"], gf["masks"], swap_and_flatten(env, ro["actions"]),
+               gf["values"], gf["neglogp"], mb_states, ep_infos, gf["rewards"])
         if self.reset_after_run:
             self.obs = env.reset()                                                         # ppo2.py:525
         return out

@@ -52,7 +52,8 @@ class VecDockingEnv:
     def __init__(self, env_id="docking-v0", num_envs=1, device=0, integrator="frozen", dt=0.02,
                  auto_reset=True, randomise=0, seed=0, env_id_offset=0, init_range=(0.0, 0.0, 0.0, 0.0),
                  mass_scale=(1.0, 1.0), inertia_scale=(1.0, 1.0), mass=0.18,
-                 inertia=(0.00025, 0.000232, 0.0003738), backend="torch", use_torch_stream=True):
+                 inertia=(0.00025, 0.000232, 0.0003738), backend="torch", use_torch_stream=True, copy=True,
+                 info_state=False):
         if env_id not in _KINDS:
             raise ValueError("unknown env id %r (have %s)" % (env_id, sorted(_KINDS)))
         if backend not in ("torch", "numpy"):
@@ -87,6 +88,13 @@ class VecDockingEnv:
         cfg.inertia_scale = (C.c_float * 2)(*inertia_scale)
         cfg.mass = mass
         cfg.inertia = (C.c_float * 3)(*inertia)
+        # copy=True (default): step() hands out tensors nobody else writes to -- every step's outputs are written by the
+        # kernel straight into freshly allocated tensors (no device copy), as SB2's VecEnvs hand out fresh arrays.
+        # copy=False: views of the env's own buffers, valid until the next step (saves ~6 allocator calls per step).
+        self.copy = bool(copy)
+        # info_state=True: infos[i]['chaser'/'target'] of envs that did NOT finish are snapshotted at every step (one
+        # extra kernel); False: they are fetched when first asked for, which must happen before the next step
+        self.info_state = bool(info_state)
         self._follow_torch_stream = bool(use_torch_stream)
         self._stream = None
         if use_torch_stream:
@@ -103,7 +111,10 @@ class VecDockingEnv:
         self._done = torch.empty((n,), dtype=torch.uint8, **kw)
         self._flags = torch.empty((n,), dtype=torch.uint8, **kw)
         self._term = torch.zeros((n, self.obs_dim), dtype=torch.float32, **kw)
+        self._tstate = None if self.kind == _lib.KIND_HOVER else torch.zeros((n, 26), dtype=torch.float32, **kw)
         self._actions = None
+        self._nstep = 0                                 # steps issued (InfoView staleness guard)
+        self._groups = None
         self._pin, self._pin_i, self._act_pin = None, 0, None
         self.auto_reset = bool(auto_reset)
         # attribute surface the reference scripts poke (run_trained_docking_ppo2.py:45)
@@ -142,6 +153,16 @@ class VecDockingEnv:
                 _lib.check(self._lib.qs_set_stream(self._h, C.c_void_p(s) if s else None, 1), "qs_set_stream")
                 self._stream = s
 
+    def _outputs_ready(self):
+        """an owned (non-torch) stream is not ordered with torch's: drain it before torch touches what a kernel wrote"""
+        if not self._follow_torch_stream:
+            self.sync()
+
+    def _inputs_ready(self):
+        """... and make sure torch has finished producing the inputs before a kernel on the owned stream reads them"""
+        if not self._follow_torch_stream:
+            _torch().cuda.current_stream(self.device).synchronize()
+
     def close(self):
         if getattr(self, "_h", None) is not None and self._h:
             self._lib.qs_destroy(self._h)
@@ -163,14 +184,16 @@ class VecDockingEnv:
         m = None
         if mask is not None:
             m = self._as_device(mask, (self.num_envs,), _torch().uint8)
+        self._inputs_ready()
         _lib.check(self._lib.qs_reset(self._h, self._ptr(m), self._ptr(self._obs)), "qs_reset")
+        self._outputs_ready()
         return self._out(self._obs.clone() if self.backend == "torch" else self._obs)
 
     def step_async(self, actions):
         self._use_current_stream()
+        torch = _torch()
         if self.backend == "numpy" and isinstance(actions, np.ndarray):
             # host actions: through a pinned staging tensor, asynchronously (no pageable-memory copy on the way up)
-            torch = _torch()
             if self._act_pin is None:
                 self._act_pin = torch.empty((self.num_envs, 4), dtype=torch.float32, pin_memory=True)
                 self._act_dev = torch.empty((self.num_envs, 4), dtype=torch.float32, device=self.device)
@@ -179,32 +202,135 @@ class VecDockingEnv:
             self._actions = self._act_dev
         else:
             self._actions = self._as_device(actions, (self.num_envs, 4))
-        _lib.check(self._lib.qs_step(self._h, self._ptr(self._actions), self._ptr(self._obs), self._ptr(self._rew),
-                                     self._ptr(self._done), self._ptr(self._flags),
-                                     self._ptr(self._term) if self.auto_reset else None), "qs_step")
+        if self.copy and self.backend == "torch":
+            # this step's outputs get tensors of their own: whatever the caller kept from earlier steps stays intact
+            n, kw = self.num_envs, dict(device=self.device)
+            self._obs = torch.empty((n, self.obs_dim), dtype=torch.float32, **kw)
+            self._rew = torch.empty((n,), dtype=torch.float32, **kw)
+            self._done = torch.empty((n,), dtype=torch.uint8, **kw)
+            self._flags = torch.empty((n,), dtype=torch.uint8, **kw)
+            if self.auto_reset:
+                self._term = torch.empty((n, self.obs_dim), dtype=torch.float32, **kw)
+                if self._tstate is not None:
+                    self._tstate = torch.empty((n, 26), dtype=torch.float32, **kw)
+        self._inputs_ready()
+        _lib.check(self._lib.qs_step_ex(self._h, self._ptr(self._actions), self._ptr(self._obs), self._ptr(self._rew),
+                                        self._ptr(self._done), self._ptr(self._flags),
+                                        self._ptr(self._term) if self.auto_reset else None,
+                                        self._ptr(self._tstate) if self.auto_reset else None), "qs_step")
+        self._nstep += 1
 
     def step_wait(self):
+        self._outputs_ready()
         if self.backend == "torch":
-            # views of the env's own buffers (valid until the next step); done is the uint8 buffer seen as bool
-            return self._obs, self._rew, self._done.view(_torch().bool), InfoView(self)
-        # numpy backend: four async copies into pinned host mirrors, ONE stream sync.  Two sets of mirrors alternate,
+            # done is the uint8 buffer seen as bool.  The InfoView keeps THIS step's tensors (done, flags, terminal
+            # observation / states): with copy=True they are never written again, so it can be read at any time
+            infos = InfoView(self, done_t=self._done, flags_t=self._flags, term_t=self._term, tstate_t=self._tstate)
+            return self._obs, self._rew, self._done.view(_torch().bool), infos
+        # numpy backend: async copies into pinned host mirrors, ONE stream sync.  Two sets of mirrors alternate,
         # so the arrays of a step stay valid until the step after the next one (SB2's runner copies them at once).
         torch = _torch()
+        srcs = [self._obs, self._rew, self._done, self._flags, self._term] + ([self._tstate] if self._tstate is not None else [])
         if self._pin is None:
             mk = lambda t: torch.empty(t.shape, dtype=t.dtype, pin_memory=True)                 # noqa: E731
-            self._pin = [[mk(t) for t in (self._obs, self._rew, self._done, self._flags)] for _ in range(2)]
+            self._pin = [[mk(t) for t in srcs] for _ in range(2)]
         self._pin_i ^= 1
         h = self._pin[self._pin_i]
-        for dst, src in zip(h, (self._obs, self._rew, self._done, self._flags)):
+        for dst, src in zip(h, srcs[:4] if not self.auto_reset else srcs):
             dst.copy_(src, non_blocking=True)
         torch.cuda.current_stream(self.device).synchronize()
         obs, rew, done, flags = h[0].numpy(), h[1].numpy(), h[2].numpy().view(np.bool_), h[3].numpy()
-        infos = InfoView(self, done=done, flags=flags)
+        if self.copy:
+            obs, rew, done = obs.copy(), rew.copy(), done.copy()
+        # terminal rows are only meaningful where done: copy those out of the mirror (it is recycled two steps later)
+        term = tstate = None
+        if self.auto_reset and done.any():
+            term = h[4].numpy().copy()
+            tstate = h[5].numpy().copy() if self._tstate is not None else None
+        infos = InfoView(self, done=done, flags=flags.copy(), term=term, tstate=tstate)
         return obs, rew, done, infos
 
     def step(self, actions):
         self.step_async(actions)
         return self.step_wait()
+
+    # ------------------------------------------------------------------ env groups (EnvPool-style send / recv)
+    def set_groups(self, groups, threads=True):
+        """Partition the envs into `groups` contiguous groups, each stepped on its own stream (qs_set_groups): the step
+        of one group overlaps the kernel boundary -- or the policy -- of the others.  groups <= 1 removes the grouping.
+        threads: one native launcher thread per group (the calling thread only posts launch records).
+        Results are bit-identical to step() for any grouping."""
+        self._use_current_stream()
+        _lib.check(self._lib.qs_set_groups(self._h, int(groups), 1 if threads else 0), "qs_set_groups")
+        self._groups = None
+        k = C.c_int32(0)
+        _lib.check(self._lib.qs_group_count(self._h, C.byref(k)), "qs_group_count")
+        if groups > 1:
+            torch = _torch()
+            self._groups = []
+            for g in range(k.value):
+                lo, hi, sp = C.c_int64(0), C.c_int64(0), C.c_void_p()
+                _lib.check(self._lib.qs_group_range(self._h, g, C.byref(lo), C.byref(hi)), "qs_group_range")
+                _lib.check(self._lib.qs_group_stream(self._h, g, C.byref(sp)), "qs_group_stream")
+                self._groups.append({"range": (lo.value, hi.value), "stream_ptr": sp.value,
+                                     "stream": torch.cuda.ExternalStream(sp.value, device=self.device)})
+        return k.value
+
+    @property
+    def num_groups(self):
+        return len(self._groups) if self._groups else 1
+
+    def group_range(self, g):
+        """[start, stop) env ids of group g"""
+        return self._groups[g]["range"] if self._groups else (0, self.num_envs)
+
+    def group_stream(self, g):
+        """torch stream of group g: run that group's policy under `with torch.cuda.stream(env.group_stream(g))` and its
+        steps need no cross-stream ordering at all"""
+        return self._groups[g]["stream"]
+
+    def step_group(self, g, actions):
+        """one step of group g, enqueued on the group's stream.  actions [n_g,4] (a tensor produced on that stream, or
+        ordered before it by the caller).  -> (obs [n_g,12], reward [n_g], done [n_g] bool, flags [n_g] u8, terminal_obs
+        [n_g,12], terminal_state [n_g,26]) fresh tensors owned by the group's stream."""
+        torch = _torch()
+        G = self._groups[g]
+        lo, hi = G["range"]
+        n = hi - lo
+        actions = self._as_device(actions, (n, 4))
+        with torch.cuda.stream(G["stream"]):
+            kw = dict(device=self.device)
+            obs = torch.empty((n, self.obs_dim), dtype=torch.float32, **kw)
+            rew = torch.empty((n,), dtype=torch.float32, **kw)
+            done = torch.empty((n,), dtype=torch.uint8, **kw)
+            flags = torch.empty((n,), dtype=torch.uint8, **kw)
+            term = torch.empty((n, self.obs_dim), dtype=torch.float32, **kw) if self.auto_reset else None
+            tst = torch.empty((n, 26), dtype=torch.float32, **kw) if (self.auto_reset and self._tstate is not None) else None
+        _lib.check(self._lib.qs_step_group(self._h, g, self._ptr(actions), self._ptr(obs), self._ptr(rew), self._ptr(done),
+                                           self._ptr(flags), self._ptr(term), self._ptr(tst)), "qs_step_group")
+        self._nstep += 1
+        return obs, rew, done.view(torch.bool), flags, term, tst
+
+    def step_groups(self, actions):
+        """one step of ALL groups in one call (G launches, one per group stream), full-batch tensors as step(); the
+        outputs are the env's own buffers, complete once groups_join() / sync() has ordered the group streams"""
+        self._actions = self._as_device(actions, (self.num_envs, 4))
+        _lib.check(self._lib.qs_step_groups(self._h, self._ptr(self._actions), self._ptr(self._obs), self._ptr(self._rew),
+                                            self._ptr(self._done), self._ptr(self._flags),
+                                            self._ptr(self._term) if self.auto_reset else None,
+                                            self._ptr(self._tstate) if self.auto_reset else None), "qs_step_groups")
+        self._nstep += 1
+        return self._obs, self._rew, self._done.view(_torch().bool)
+
+    def groups_fork(self):
+        """group streams wait for everything enqueued so far on the env's main stream (torch's current stream)"""
+        self._use_current_stream()
+        _lib.check(self._lib.qs_groups_fork(self._h), "qs_groups_fork")
+
+    def groups_join(self):
+        """the env's main stream waits for everything enqueued so far on the group streams"""
+        self._use_current_stream()
+        _lib.check(self._lib.qs_groups_join(self._h), "qs_groups_join")
 
     def rollout(self, actions=None, T=None, want_flags=True, stepwise=False, out=None):
         """T fused steps in one launch (qs_rollout), or T single-step launches issued from native code
@@ -227,8 +353,10 @@ class VecDockingEnv:
             done = torch.empty((T, n), dtype=torch.uint8, device=self.device)
             flags = torch.empty((T, n), dtype=torch.uint8, device=self.device) if want_flags else None
         fn = self._lib.qs_rollout_stepwise if stepwise else self._lib.qs_rollout
+        self._inputs_ready()
         _lib.check(fn(self._h, T, self._ptr(actions), self._ptr(obs), self._ptr(rew), self._ptr(done),
                       self._ptr(flags)), "qs_rollout")
+        self._outputs_ready()
         return obs, rew, done, flags
 
     def rollout_slab(self, actions=None, T=None, out=None):
@@ -241,7 +369,9 @@ class VecDockingEnv:
         elif T is None:
             raise ValueError("give actions or T")
         slab = out if out is not None else torch.empty((T, self.num_envs, 14), dtype=torch.float32, device=self.device)
+        self._inputs_ready()
         _lib.check(self._lib.qs_rollout_slab(self._h, T, self._ptr(actions), self._ptr(slab), None), "qs_rollout_slab")
+        self._outputs_ready()
         return slab
 
     def random_actions(self, T, step0=None):
@@ -249,8 +379,10 @@ class VecDockingEnv:
         torch = _torch()
         if step0 is None:
             step0 = self.step_counter
+        self._use_current_stream()
         a = torch.empty((T, self.num_envs, 4), dtype=torch.float32, device=self.device)
         _lib.check(self._lib.qs_fill_random_actions(self._h, T, int(step0), self._ptr(a)), "qs_fill_random_actions")
+        self._outputs_ready()
         return a
 
     def seed(self, seed=None):
@@ -304,14 +436,17 @@ class VecDockingEnv:
         torch = _torch()
         n = self.num_envs
         shapes = dict(chaser=(n, 13), target=(n, 13), u_prev=(n, 8), qdes=(n, 4), last_shaping=(n,), t=(n,))
+        self._use_current_stream()
         bufs = {k: torch.empty(s, dtype=torch.float32, device=self.device) for k, s in shapes.items()}
         _lib.check(self._lib.qs_get_state(self._h, *[self._ptr(bufs[k]) for k in shapes]), "qs_get_state")
+        self._outputs_ready()
         return {k: (v.cpu().numpy() if as_numpy else v) for k, v in bufs.items()}
 
     def set_state(self, chaser=None, target=None, u_prev=None, qdes=None, last_shaping=None, t=None):
         n = self.num_envs
         shapes = dict(chaser=(n, 13), target=(n, 13), u_prev=(n, 8), qdes=(n, 4), last_shaping=(n,), t=(n,))
         given = dict(chaser=chaser, target=target, u_prev=u_prev, qdes=qdes, last_shaping=last_shaping, t=t)
+        self._use_current_stream()
         ptrs, keep = [], []
         for k, s in shapes.items():
             if given[k] is None:
@@ -320,19 +455,23 @@ class VecDockingEnv:
                 tt = self._as_device(given[k], s)
                 keep.append(tt)
                 ptrs.append(self._ptr(tt))
+        self._inputs_ready()
         _lib.check(self._lib.qs_set_state(self._h, *ptrs), "qs_set_state")
         self.sync()
 
     def set_init_state(self, chaser_init, target_init=None):
         """per-env initial states reset() returns to (env.chaser_ini_state / target_ini_state; HoveringEnv.ini_state)"""
         n = self.num_envs
+        self._use_current_stream()
         c = self._as_device(chaser_init, (n, 13))
         t = self._as_device(target_init, (n, 13)) if target_init is not None else None
+        self._inputs_ready()
         _lib.check(self._lib.qs_set_init_state(self._h, self._ptr(c), self._ptr(t)), "qs_set_init_state")
 
     def get_init_state(self):
         torch = _torch()
         n = self.num_envs
+        self._use_current_stream()
         c = torch.empty((n, 13), dtype=torch.float32, device=self.device)
         t = torch.empty((n, 13), dtype=torch.float32, device=self.device)
         _lib.check(self._lib.qs_get_init_state(self._h, self._ptr(c), self._ptr(t)), "qs_get_init_state")
@@ -340,17 +479,21 @@ class VecDockingEnv:
 
     def set_params(self, mass=None, inertia=None):
         n = self.num_envs
+        self._use_current_stream()
         m = self._as_device(mass, (n,)) if mass is not None else None
         i = self._as_device(inertia, (n, 3)) if inertia is not None else None
+        self._inputs_ready()
         _lib.check(self._lib.qs_set_params(self._h, self._ptr(m), self._ptr(i)), "qs_set_params")
         self.sync()
 
     def get_params(self):
         torch = _torch()
         n = self.num_envs
+        self._use_current_stream()
         m = torch.empty((n,), dtype=torch.float32, device=self.device)
         i = torch.empty((n, 3), dtype=torch.float32, device=self.device)
         _lib.check(self._lib.qs_get_params(self._h, self._ptr(m), self._ptr(i)), "qs_get_params")
+        self._outputs_ready()
         return m.cpu().numpy(), i.cpu().numpy()
 
     def timer_start(self):
@@ -365,36 +508,77 @@ class VecDockingEnv:
 class InfoView:
     """infos[i] of the VecEnv protocol, materialised lazily: building N dicts per
     step would dominate the step at N = 65 536.  infos[i] is a dict with the
-    reference's keys (docking_env.py:226-229) plus SB2's 'terminal_observation'."""
+    reference's keys (docking_env.py:226-229) plus SB2's 'terminal_observation'.
 
-    def __init__(self, env, done=None, flags=None):
+    What belongs to THIS step is captured when step_wait() returns: done, flags, and -- for the envs that finished --
+    the terminal observation and the terminal chaser / target states (written by the step kernel before its in-kernel
+    reset: info['chaser'] is the state the reference's env returns on the done step, not the reset state).  The
+    states of envs that did not finish are the env's current states: snapshotted per step with
+    VecDockingEnv(info_state=True), else fetched on first access, which must come before the next step."""
+
+    def __init__(self, env, done=None, flags=None, term=None, tstate=None, done_t=None, flags_t=None, term_t=None,
+                 tstate_t=None):
         self._env = env
-        self._done, self._flags = done, flags
-        self._term = None
+        self._done, self._flags, self._term, self._tstate = done, flags, term, tstate        # host arrays
+        self._dev = (done_t, flags_t, term_t, tstate_t)                                       # this step's device tensors
+        self._step = env._nstep
         self._state = None
+        if env.backend == "torch" and not env.copy:
+            # the env's buffers are rewritten by the next step: take this step's small per-env flags now (two [N] u8
+            # copies, stream-ordered, no host sync); terminal rows are fetched on access and guarded by the step count
+            self._dev = (done_t.clone(), flags_t.clone(), term_t, tstate_t)
+        if env.info_state and env.kind != _lib.KIND_HOVER:
+            st = env.get_state(as_numpy=False)
+            self._state_dev = (st["chaser"], st["target"])
+        else:
+            self._state_dev = None
 
     def __len__(self):
         return self._env.num_envs
 
+    def _stale(self):
+        return self._env._nstep != self._step
+
     def _materialise(self):
-        e = self._env
+        d, f, tm, ts = self._dev
         if self._done is None:
-            self._done = e._done.cpu().numpy().astype(bool)
-            self._flags = e._flags.cpu().numpy()
-        if self._term is None:
-            self._term = e._term.cpu().numpy()
+            self._done = d.cpu().numpy().astype(bool)
+            self._flags = f.cpu().numpy()
+        if self._term is None and self._env.auto_reset and self._done.any():
+            if self._stale() and not self._env.copy:
+                raise _lib.QuadsimError("this InfoView is read after a later step of a copy=False env: its terminal rows "
+                                        "were recycled; read infos before stepping again or use copy=True")
+            self._term = tm.cpu().numpy()
+            self._tstate = ts.cpu().numpy() if ts is not None else None
+
+    def _states(self):
+        if self._state is None:
+            if self._state_dev is not None:
+                self._state = {"chaser": self._state_dev[0].cpu().numpy(), "target": self._state_dev[1].cpu().numpy()}
+            else:
+                if self._stale():
+                    raise _lib.QuadsimError("info['chaser'/'target'] of an env that did not finish is the env's current state; "
+                                            "this InfoView is read after a later step.  Read it before the next step or "
+                                            "create the env with info_state=True")
+                self._state = self._env.get_state()
+        return self._state
 
     def __getitem__(self, i):
         self._materialise()
-        if self._state is None:
-            self._state = self._env.get_state()
         f = int(self._flags[i])
+        finished = bool(self._done[i]) and self._env.auto_reset
         if self._env.kind == _lib.KIND_HOVER:
             info = {}                                         # hovering_env.py:78 returns an empty info
         else:
-            info = {"chaser": self._state["chaser"][i], "target": self._state["target"][i],
+            if finished:
+                # docking_env.py:226-229: the states of the TERMINAL step (the in-kernel reset has already replaced them)
+                chaser, target = self._tstate[i, :13].copy(), self._tstate[i, 13:].copy()
+            else:
+                st = self._states()
+                chaser, target = st["chaser"][i], st["target"][i]
+            info = {"chaser": chaser, "target": target,
                     "flag_docking": bool(f & _lib.FLAG_DOCKED), "done_overlimit": bool(f & _lib.FLAG_OVERLIMIT)}
-        if self._done[i] and self._env.auto_reset:
+        if finished:
             info["terminal_observation"] = self._term[i].copy()
         return info
 
@@ -405,3 +589,9 @@ class InfoView:
     def flags(self):
         self._materialise()
         return self._flags
+
+    @property
+    def terminal_states(self):
+        """[N,26] chaser | target of the terminal step (rows of envs that did not finish are undefined); None if no env finished"""
+        self._materialise()
+        return self._tstate

@@ -1,0 +1,344 @@
+"""-m gpu: env groups (several step chains of one handle in flight), terminal states of the VecEnv contract,
+the fused GAE + flatten and episode-accounting kernels, and Runner.run() at the shape of tools/soak_runner.py.
+All through the C ABI; references are the fixtures of the NumPy reference, the CPU oracle, or plain torch ops."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import load_golden
+from helpers import OBS_TOL, STATE_TOL, set_env_from_rec, threshold_margin
+from oracle.pyoracle import episode_stats_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def qa():
+    import quadsim_amd
+    return quadsim_amd
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    return torch
+
+
+def _full_state(env):
+    st = env.get_state()
+    return np.concatenate([st["chaser"], st["target"], st["u_prev"], st["qdes"], st["last_shaping"][:, None], st["t"][:, None]], 1)
+
+
+# ---------------------------------------------------------------- env groups
+@pytest.mark.parametrize("n,groups,threads,env_id,rnd", [
+    (65536, 2, True, "docking-v0", 1), (65536, 4, False, "docking-v0", 1), (1000, 3, True, "docking-v2", 2),
+    (4096, 2, False, "docking-v0", 0), (200, 7, True, "docking-v2", 1), (262144, 2, True, "docking-v0", 1)])
+def test_step_groups_bit_identical_to_single_launch(qa, torch, n, groups, threads, env_id, rnd):
+    """G chains on G streams (qs_step_groups) == one qs_step launch, bit for bit: outputs of every step, terminal
+    rows, the final state and the step counter -- any grouping, launcher threads or not, ragged tail tiles included"""
+    kw = dict(num_envs=n, randomise=rnd, seed=11, init_range=qa.C3_INIT_RANGE, mass_scale=(0.8, 1.2),
+              inertia_scale=(0.8, 1.2), env_id_offset=12345, copy=False)
+    a, b = qa.VecDockingEnv(env_id, **kw), qa.VecDockingEnv(env_id, **kw)
+    a.reset(); b.reset()
+    t0 = np.zeros(n, np.float32); t0[::5] = 596.0          # a fifth of the envs time out inside the window
+    a.set_state(t=t0); b.set_state(t=t0)
+    got = b.set_groups(groups, threads=threads)
+    assert got == min(groups, (n + 63) // 64)
+    lo_hi = [b.group_range(g) for g in range(b.num_groups)]
+    assert lo_hi[0][0] == 0 and lo_hi[-1][1] == n and all(x[1] == y[0] for x, y in zip(lo_hi, lo_hi[1:]))
+    T = 6
+    acts = a.random_actions(T, step0=0)
+    n_done = 0
+    for k in range(T):
+        oa, ra, da, ia = a.step(acts[k])
+        ob, rb, db = b.step_groups(acts[k])
+        b.groups_join()
+        torch.cuda.synchronize()
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db)
+        assert torch.equal(a._flags, b._flags)
+        d = da.cpu().numpy()
+        if d.any():
+            assert torch.equal(a._term[da], b._term[db]) and torch.equal(a._tstate[da], b._tstate[db])
+        n_done += int(d.sum())
+    assert n_done >= n // 6
+    assert a.step_counter == b.step_counter == T
+    np.testing.assert_array_equal(_full_state(a), _full_state(b))
+    b.set_groups(1)                                          # back to one launch per step: still the same chain
+    oa, _, _, _ = a.step(acts[0]); ob, _, _, _ = b.step(acts[0])
+    assert torch.equal(oa, ob)
+    a.close(); b.close()
+
+
+def test_step_group_with_group_local_tensors_and_streams(qa, torch):
+    """EnvPool-style use: every group is stepped on its own stream with its own [n_g,...] tensors, the 'policy'
+    (here: a torch op producing the actions) runs on the same stream; equals the single-launch env"""
+    n = 3000
+    kw = dict(num_envs=n, randomise=1, seed=3, init_range=qa.C3_INIT_RANGE)
+    a, b = qa.VecDockingEnv("docking-v0", **kw), qa.VecDockingEnv("docking-v0", **kw)
+    a.reset(); b.reset()
+    b.set_groups(3, threads=True)
+    acts = a.random_actions(4, step0=0)
+    for k in range(4):
+        oa, ra, da, _ = a.step(acts[k])
+        b.groups_fork()                                       # acts[k] was produced on the main stream
+        outs = []
+        for g in range(b.num_groups):
+            lo, hi = b.group_range(g)
+            with torch.cuda.stream(b.group_stream(g)):
+                ag = (acts[k, lo:hi] * 1.0).contiguous()      # the group's policy, on the group's stream
+            outs.append(b.step_group(g, ag))
+        b.groups_join()
+        torch.cuda.synchronize()
+        ob = torch.cat([o[0] for o in outs]); rb = torch.cat([o[1] for o in outs]); db = torch.cat([o[2] for o in outs])
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db)
+    np.testing.assert_array_equal(_full_state(a), _full_state(b))
+    a.close(); b.close()
+
+
+def test_groups_survive_main_stream_calls_in_between(qa, torch):
+    """reset / set_state / get_state between group steps are ordered automatically (implicit join and fork)"""
+    n = 2048
+    a = qa.VecDockingEnv("docking-v0", num_envs=n, randomise=1, seed=5, init_range=qa.C3_INIT_RANGE, copy=False)
+    b = qa.VecDockingEnv("docking-v0", num_envs=n, randomise=1, seed=5, init_range=qa.C3_INIT_RANGE, copy=False)
+    b.set_groups(2, threads=True)
+    acts = a.random_actions(3, step0=0)
+    for env, step in ((a, lambda e, x: e.step(x)), (b, lambda e, x: e.step_groups(x))):
+        env.reset()
+        step(env, acts[0])
+        mask = np.zeros(n, np.uint8); mask[::3] = 1
+        env.reset(mask)                                       # main-stream call right behind a group step
+        step(env, acts[1])
+        st = env.get_state()                                  # ... and a read-back right behind another
+        env.set_state(t=st["t"] + 100.0)
+        step(env, acts[2])
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(_full_state(a), _full_state(b))
+    assert torch.equal(a._obs, b._obs)
+    a.close(); b.close()
+
+
+# ---------------------------------------------------------------- VecEnv contract: terminal states, fresh outputs
+@pytest.mark.parametrize("name,env_id,kind", [("g4_traj_v0", "docking-v0", 0), ("g4_traj_v2", "docking-v2", 1)])
+def test_info_chaser_target_on_done_steps_are_the_terminal_states(qa, name, env_id, kind):
+    """docking_env.py:226-229: info['chaser'] / info['target'] of a done step are the states OF that step.  Every
+    recorded reference step is replayed as one env of an auto-resetting batch: on done rows the infos must carry the
+    reference's rec_after (the state before SB2's worker resets), while the env itself already holds the reset state."""
+    g = load_golden(name)
+    n = len(g["rec_before"])
+    env = qa.VecDockingEnv(env_id, num_envs=n, auto_reset=True)
+    set_env_from_rec(env, g["rec_before"])
+    obs, rew, done, infos = env.step(g["actions"])
+    done = done.cpu().numpy()
+    rmax = 3.0 if kind == 0 else 10.0
+    safe = threshold_margin(g["obs"], g["rec_after"][:, 2], g["rec_after"][:, 39], rmax) > 1e-4
+    assert np.array_equal(done[safe], g["done"][safe].astype(bool))
+    idx = np.nonzero(done & safe)[0]
+    assert len(idx) >= 10
+    now = env.get_state()
+    for i in idx:
+        info = infos[int(i)]
+        np.testing.assert_allclose(info["chaser"], g["rec_after"][i, 0:13], **STATE_TOL)
+        np.testing.assert_allclose(info["target"], g["rec_after"][i, 13:26], **STATE_TOL)
+        np.testing.assert_allclose(info["terminal_observation"], g["obs"][i], **OBS_TOL)
+        np.testing.assert_allclose(now["chaser"][i, :3], [8.0, -50.0, 5.0], atol=1e-6)     # the env itself was reset
+        np.testing.assert_allclose(obs[i].cpu().numpy(), g["reset_obs"][i], atol=2e-6)
+    j = int(np.nonzero(~done)[0][0])
+    np.testing.assert_allclose(infos[j]["chaser"], g["rec_after"][j, 0:13], **STATE_TOL)   # not done: the current state
+    assert "terminal_observation" not in infos[j]
+    env.close()
+
+
+def test_step_outputs_are_not_aliased_by_default(qa, torch):
+    n = 512
+    env = qa.VecDockingEnv("docking-v0", num_envs=n, randomise=1, seed=2, init_range=qa.C3_INIT_RANGE)
+    env.reset()
+    t0 = np.zeros(n, np.float32); t0[::2] = 599.0
+    env.set_state(t=t0)
+    acts = env.random_actions(3, step0=0)
+    o1, r1, d1, i1 = env.step(acts[0])
+    keep = (o1.clone(), r1.clone(), d1.clone())
+    o2, r2, d2, i2 = env.step(acts[1])
+    assert o1.data_ptr() != o2.data_ptr()
+    assert torch.equal(o1, keep[0]) and torch.equal(r1, keep[1]) and torch.equal(d1, keep[2])
+    assert d1[0].item() and "terminal_observation" in i1[0]          # the first step's infos survive the second step
+    assert np.allclose(i1[0]["chaser"][6], 1.0, atol=0.1)
+    with pytest.raises(qa.QuadsimError):
+        i1[1]                                                         # a not-done env's state is gone after the next step
+    env.close()
+    env = qa.VecDockingEnv("docking-v0", num_envs=n, randomise=1, seed=2, init_range=qa.C3_INIT_RANGE, copy=False,
+                           info_state=True)
+    env.reset()
+    o1, _, _, i1 = env.step(acts[0]); o2, _, _, _ = env.step(acts[1])
+    assert o1.data_ptr() == o2.data_ptr()                             # the documented fast path re-uses its buffers
+    assert i1[1]["chaser"].shape == (13,)                             # info_state=True snapshots every step
+    env.close()
+
+
+def test_numpy_backend_reports_terminal_states(qa):
+    g = load_golden("g4_traj_v0")
+    n = len(g["rec_before"])
+    env = qa.VecDockingEnv("docking-v0", num_envs=n, auto_reset=True, backend="numpy")
+    set_env_from_rec(env, g["rec_before"])
+    obs, rew, done, infos = env.step(g["actions"].astype(np.float32))
+    safe = threshold_margin(g["obs"], g["rec_after"][:, 2], g["rec_after"][:, 39], 3.0) > 1e-4
+    i = int(np.nonzero(done & safe)[0][0])
+    np.testing.assert_allclose(infos[i]["chaser"], g["rec_after"][i, 0:13], **STATE_TOL)
+    np.testing.assert_allclose(infos[i]["target"], g["rec_after"][i, 13:26], **STATE_TOL)
+    env.close()
+
+
+# ---------------------------------------------------------------- GAE + flatten in one pass, episode accounting
+def test_gae_flatten_reproduces_the_reference_lines(qa, torch):
+    """fixture g10 = outputs of rl_baselines/ppo2/ppo2.py:507-520,531-539 executed by the generator"""
+    g = load_golden("g10_gae")
+    env = qa.VecDockingEnv("docking-v0", num_envs=64)
+    for c in ("c0", "c1", "c2", "c3"):
+        rew, val, dn = g[c + "_rewards"], g[c + "_values"], g[c + "_dones"]
+        T, n = rew.shape
+        gamma, lam = [float(x) for x in g[c + "_gamma_lam"]]
+        nl = np.random.RandomState(1).randn(T, n).astype(np.float32)
+        out = qa.gae_and_flatten(env, torch.as_tensor(rew), torch.as_tensor(val), torch.as_tensor(nl), torch.as_tensor(dn),
+                                 torch.as_tensor(g[c + "_last_values"]), torch.as_tensor(g[c + "_last_dones"]), gamma, lam,
+                                 want_advs=True)
+        np.testing.assert_allclose(out["advs"].cpu().numpy(), g[c + "_advs"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(out["returns_tm"].cpu().numpy(), g[c + "_returns"], rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(out["returns"].cpu().numpy(), g[c + "_flat_returns"], rtol=1e-5, atol=1e-5)
+        sf = lambda x: np.ascontiguousarray(np.swapaxes(x, 0, 1)).reshape(-1)       # noqa: E731  ppo2.py:531-539
+        np.testing.assert_array_equal(out["values"].cpu().numpy(), sf(val.astype(np.float32)))
+        np.testing.assert_array_equal(out["rewards"].cpu().numpy(), sf(rew.astype(np.float32)))
+        np.testing.assert_array_equal(out["neglogp"].cpu().numpy(), sf(nl))
+        np.testing.assert_array_equal(out["masks"].cpu().numpy(), sf(dn.astype(bool)))
+    env.close()
+
+
+@pytest.mark.parametrize("T,n", [(600, 1000), (37, 257), (16, 64), (15, 70), (128, 20000), (3, 5)])
+def test_gae_flatten_equals_gae_plus_flatten(qa, torch, T, n):
+    """ragged shapes (T not a multiple of 16 or 4, N not a multiple of 256 / 32): the one-pass kernel == qs_gae followed
+    by swap_and_flatten (bit for bit against qs_gae's single-pass scan, n >= 16 384; to rounding against its two-pass
+    chunked scan below that), the pass-through arrays bit for bit, and the u8 flatten == torch"""
+    env = qa.VecDockingEnv("docking-v0", num_envs=64)
+    rs = np.random.RandomState(T * 1000 + n)
+    dev = env.device
+    rew = torch.as_tensor(rs.randn(T, n).astype(np.float32)).to(dev)
+    val = torch.as_tensor(rs.randn(T, n).astype(np.float32)).to(dev)
+    nl = torch.as_tensor(rs.randn(T, n).astype(np.float32)).to(dev)
+    dn = torch.as_tensor((rs.rand(T, n) < 0.05).astype(np.uint8)).to(dev)
+    lv = torch.as_tensor(rs.randn(n).astype(np.float32)).to(dev)
+    ld = torch.as_tensor((rs.rand(n) < 0.05).astype(np.uint8)).to(dev)
+    out = qa.gae_and_flatten(env, rew, val, nl, dn, lv, ld, 0.99, 0.95, want_advs=True)
+    advs, rets = qa.compute_gae(env, rew, val, dn, lv, ld, 0.99, 0.95)
+    if n >= 16384:
+        assert torch.equal(out["advs"], advs) and torch.equal(out["returns_tm"], rets)
+    else:
+        assert torch.allclose(out["advs"], advs, rtol=1e-5, atol=1e-5) and torch.allclose(out["returns_tm"], rets, rtol=1e-5, atol=1e-5)
+    ref = lambda x: x.swapaxes(0, 1).reshape(-1)                                         # noqa: E731
+    assert torch.equal(out["returns"], ref(out["returns_tm"])) and torch.equal(out["values"], ref(val))
+    assert torch.equal(out["neglogp"], ref(nl)) and torch.equal(out["rewards"], ref(rew))
+    assert torch.equal(out["masks"], ref(dn).bool())
+    assert torch.equal(qa.swap_and_flatten(env, rets), ref(rets))
+    f8 = qa.swap_and_flatten(env, dn)
+    assert f8.dtype == torch.uint8 and torch.equal(f8, ref(dn))
+    assert torch.equal(qa.swap_and_flatten(env, dn.bool()), ref(dn).bool())
+    env.close()
+
+
+def test_episode_stats_kernel_across_runs(qa, torch):
+    """qs_episode_stats against the plain restatement (oracle.pyoracle.episode_stats_ref): three consecutive roll-outs
+    (the second without any episode end), unfinished episodes carried on the device, (step, env) order after the sort"""
+    from quadsim_amd.rollout_buffer import EpisodeTracker
+    n, T = 1000, 25
+    env = qa.VecDockingEnv("docking-v0", num_envs=n)
+    tr = EpisodeTracker(env)
+    rng = np.random.RandomState(4)
+    ep_ret, ep_len = np.zeros(n), np.zeros(n, np.int64)
+    for it in range(3):
+        rew = rng.randn(T, n).astype(np.float32)
+        p = 0.0 if it == 1 else 0.1
+        dones = (rng.rand(T, n) < p).astype(np.uint8)
+        last = (rng.rand(n) < p).astype(np.uint8)
+        want = episode_stats_ref(rew, dones, last, ep_ret, ep_len)
+        tr.update(torch.as_tensor(rew), torch.as_tensor(dones), torch.as_tensor(last))
+        assert tr.count == len(want)
+        ret, ln, key = [x.cpu().numpy() for x in tr.results(ordered=True)]
+        assert np.array_equal(key, [w[0] for w in want])
+        assert np.array_equal(ln, [w[2] for w in want])
+        np.testing.assert_allclose(ret, [w[1] for w in want], atol=1e-4)
+        np.testing.assert_allclose(tr.ep_ret.cpu().numpy(), ep_ret, atol=1e-4)
+        assert np.array_equal(tr.ep_len.cpu().numpy(), ep_len)
+        r2, l2, k2 = [x.cpu().numpy() for x in tr.results(ordered=False)]        # unordered: the same multiset
+        assert np.array_equal(np.sort(k2), key)
+    env.close()
+
+
+# ---------------------------------------------------------------- Runner.run() at the soak shape
+def _runner_run_against_torch(qa, torch, n, T, rnd, precision="f32"):
+    import os
+    w = os.path.join(os.path.dirname(__file__), "golden", "policy_best_model_v0.npz")
+    model = qa.ActorCriticPolicy.from_npz(w)
+    env = qa.VecDockingEnv("docking-v0", num_envs=n, randomise=rnd, seed=3, init_range=qa.C3_INIT_RANGE,
+                           mass_scale=(0.9, 1.1), inertia_scale=(0.9, 1.1))
+    twin = qa.VecDockingEnv("docking-v0", num_envs=n, randomise=rnd, seed=3, init_range=qa.C3_INIT_RANGE,
+                            mass_scale=(0.9, 1.1), inertia_scale=(0.9, 1.1))
+    r = qa.Runner(env=env, model=model, n_steps=T, gamma=0.99, lam=0.95, collect_ep_infos=False, precision=precision)
+    twin.reset()
+    tot_len, tot_ret, tot_rew = 0, 0.0, 0.0
+    for it in range(2):
+        d_in = r.dones.clone()
+        ro = qa.fused_runner_rollout(twin, model, T, dones_in=d_in, precision=precision)    # the same roll-out, raw [T,N,.]
+        obs, returns, masks, actions, values, neglogp, states, ep_infos, rewards = r.run()
+        torch.cuda.synchronize()
+        f = lambda x: x.swapaxes(0, 1).reshape((n * T,) + tuple(x.shape[2:]))              # noqa: E731  ppo2.py:531-539
+        assert torch.equal(obs, f(ro["obs"])) and torch.equal(actions, f(ro["actions"]))
+        assert torch.equal(values, f(ro["values"])) and torch.equal(neglogp, f(ro["neglogp"]))
+        assert torch.equal(rewards, f(ro["rewards"])) and torch.equal(masks, f(ro["dones"]).bool())
+        advs, rets = qa.compute_gae(twin, ro["rewards"], ro["values"], ro["dones"], ro["last_values"], ro["last_dones"], 0.99, 0.95)
+        if n >= 16384:
+            assert torch.equal(returns, f(rets))          # qs_gae's single-pass scan: the same fma chain
+        else:
+            assert torch.allclose(returns, f(rets), rtol=1e-5, atol=1e-5)   # its two-pass chunked scan associates differently
+        for x in (obs, returns, actions, values, neglogp, rewards):
+            assert bool(torch.isfinite(x).all())
+        # episode accounting: the count equals the number of done flags, and every env-step / every reward belongs to
+        # exactly one episode (finished ones + the carried, unfinished ones)
+        after = torch.cat([ro["dones"][1:], ro["last_dones"].view(1, -1)], 0).bool()
+        assert r.last_ep_count == int(after.sum())
+        tot_len += int(r.last_ep_lengths.long().sum()) if r.last_ep_count else 0
+        tot_ret += float(r.last_ep_returns.double().sum()) if r.last_ep_count else 0.0
+        tot_rew += float(ro["rewards"].double().sum())
+        assert tot_len + int(r._episodes.ep_len.long().sum()) == (it + 1) * T * n
+        carried = float(r._episodes.ep_ret.double().sum())
+        assert abs(tot_ret + carried - tot_rew) <= 1e-3 * max(1.0, float(ro["rewards"].abs().double().sum()) * 1e-2)
+        if r.last_ep_count:
+            assert int(r.last_ep_lengths.min()) >= 1 and int(r.last_ep_lengths.max()) <= 600
+    env.close(); twin.close()
+
+
+def test_runner_run_at_the_soak_shape(qa, torch):
+    """tools/soak_runner.py's shape exactly (65 536 envs x 600 steps; T = 600 leaves a 24-row tail tile in the flatten
+    kernels), every returned array compared with the torch reference x.swapaxes(0,1).reshape(...)"""
+    _runner_run_against_torch(qa, torch, 65536, 600, 0)
+
+
+@pytest.mark.parametrize("n,T,rnd,prec", [(1000, 600, 2, "f32"), (65, 50, 1, "bf16x3"), (4097, 33, 1, "f32")])
+def test_runner_run_ragged_shapes(qa, torch, n, T, rnd, prec):
+    _runner_run_against_torch(qa, torch, n, T, rnd, prec)
+
+
+def test_c_abi_argument_checks_of_the_new_entry_points(qa):
+    lib = qa._lib.load()
+    env = qa.VecDockingEnv("docking-v0", num_envs=128)
+    h = env._h
+    assert lib.qs_step_group(h, 0, None, None, None, None, None, None, None) != 0       # no groups configured
+    assert lib.qs_set_groups(h, 65, 0) != 0
+    assert lib.qs_set_groups(h, 2, 1) == 0
+    k = C.c_int32(0); assert lib.qs_group_count(h, C.byref(k)) == 0 and k.value == 2
+    lo, hi = C.c_int64(0), C.c_int64(0)
+    assert lib.qs_group_range(h, 1, C.byref(lo), C.byref(hi)) == 0 and (lo.value, hi.value) == (64, 128)
+    assert lib.qs_group_range(h, 2, C.byref(lo), C.byref(hi)) != 0
+    assert lib.qs_step_group(h, 5, None, None, None, None, None, None, None) != 0
+    assert lib.qs_step_groups(h, None, None, None, None, None, None, None, None) != 0
+    assert lib.qs_gae_flatten(h, 0, 1, *([None] * 6), 0.99, 0.95, *([None] * 7)) != 0
+    assert lib.qs_episode_stats(h, 1, 1, *([None] * 6), 0, None, None, None) != 0
+    assert lib.qs_set_groups(h, 1, 0) == 0
+    env.close()

@@ -28,7 +28,7 @@ def test_header_symbols_are_exported_by_the_library():
     for name in declared:
         assert hasattr(lib, name), "libquadsim_hip.so does not export %s" % name
     assert sorted(_lib.EXPORTS) == declared
-    assert lib.qs_version() == 100
+    assert lib.qs_version() == 110
 
 
 def test_config_struct_matches_header():
@@ -223,29 +223,35 @@ def test_actor_critic_step_host_logic_matches_oracle():
     np.testing.assert_allclose(list(s.logstd), W["logstd"], rtol=0, atol=0)
 
 
-def test_runner_episode_bookkeeping_across_runs():
-    """Runner._episode_infos: segmented episode returns / lengths over [T,N] tensors, carried across consecutive runs"""
+def test_episode_stats_reference_known_answer():
+    """oracle.pyoracle.episode_stats_ref (the checker of qs_episode_stats) on a hand-worked case: 2 envs, 4 steps,
+    env 0 finishes after steps 1 and 3, env 1 never; the carried episode continues in the next roll-out"""
+    from oracle.pyoracle import episode_stats_ref
+    rew = np.array([[1.0, 10.0], [2.0, 20.0], [3.0, 30.0], [4.0, 40.0]])
+    dones = np.array([[0, 0], [0, 0], [1, 0], [0, 0]], np.uint8)      # flags BEFORE each step: env 0 was done after step 1
+    last = np.array([1, 0], np.uint8)                                   # ... and after step 3
+    ep_ret, ep_len = np.zeros(2), np.zeros(2, np.int64)
+    got = episode_stats_ref(rew, dones, last, ep_ret, ep_len)
+    assert got == [(1 * 2 + 0, 3.0, 2), (3 * 2 + 0, 7.0, 2)]
+    np.testing.assert_array_equal(ep_ret, [0.0, 100.0]); np.testing.assert_array_equal(ep_len, [0, 4])
+    got = episode_stats_ref(rew[:1], dones[:1], np.array([0, 1], np.uint8), ep_ret, ep_len)
+    assert got == [(1, 110.0, 5)]
+
+
+def test_bench_self_launches_ranks_without_a_launcher():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (the driver's form) must spawn its own ranks instead of
+    asking for torch.distributed.run.  On this GPU-less host each child stops at the 'needs an MI355X' check: the
+    parent has to relay that failure (non-zero exit), and must not have touched the GPU or raised the old SystemExit."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1",
+                        "--no-extras", "--no-cpu-baseline", "--spawn-timeout", "240"], env=env, capture_output=True,
+                       text=True, timeout=300)
     import torch
-    from quadsim_amd.runner import Runner
-    rng = np.random.RandomState(4)
-    n, T = 37, 25
-    r = Runner.__new__(Runner)
-    r.torch = torch; r.collect_ep_infos = True
-    r._ep_ret = torch.zeros(n); r._ep_len = torch.zeros(n, dtype=torch.int64)
-    ep_ret = np.zeros(n); ep_len = np.zeros(n, np.int64)
-    for it in range(3):
-        rew = rng.randn(T, n).astype(np.float32)
-        done = rng.rand(T, n) < (0.0 if it == 1 else 0.1)          # run 1 has no episode end at all
-        got = r._episode_infos(torch.as_tensor(rew), torch.as_tensor(done))
-        want = []
-        for t in range(T):
-            ep_ret += rew[t]; ep_len += 1
-            for i in np.nonzero(done[t])[0]:
-                want.append((ep_ret[i], ep_len[i])); ep_ret[i] = 0.0; ep_len[i] = 0
-        assert [e["l"] for e in got] == [int(l_) for _, l_ in want]
-        np.testing.assert_allclose([e["r"] for e in got], [x for x, _ in want], atol=1e-4)
-        np.testing.assert_allclose(r._ep_ret.numpy(), ep_ret, atol=1e-4)
-        assert np.array_equal(r._ep_len.numpy(), ep_len)
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by the gpu tier")
+    assert "torch.distributed.run" not in p.stderr
+    assert p.stderr.count("needs an MI355X") == 2, p.stderr[-2000:]
+    assert p.returncode != 0
 
 
 def test_packed_weight_images_match_the_library_layout():
