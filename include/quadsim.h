@@ -316,6 +316,14 @@ int qs_runner_rollout(QsEnv *env, int64_t T, const QsActorCritic *policy, const 
                       uint8_t *mb_dones /* [T,N] */, float *mb_rewards /* [T,N] */, uint8_t *mb_flags /* nullable [T,N] */,
                       float *last_obs /* nullable [N,12] */, float *last_values /* [N] */, uint8_t *last_dones /* [N] */);
 
+/* Layout of the two WIDE roll-out arrays of qs_runner_rollout(_fast), mb_obs and mb_actions:
+ *   QS_LAYOUT_TIME_MAJOR (default): [T,N,12] / [T,N,4], as the Runner loop fills them (ppo2.py:473-478);
+ *   QS_LAYOUT_ENV_MAJOR: [N,T,12] / [N,T,4] = what swap_and_flatten (ppo2.py:531-539) turns them into before the
+ *   trainer sees them -- written that way directly, so Runner.run() needs no transpose pass over them.
+ * The per-(t, env) scalars (values, neglogp, dones, rewards) stay [T,N]: qs_gae_flatten reads and flattens them. */
+enum { QS_LAYOUT_TIME_MAJOR = 0, QS_LAYOUT_ENV_MAJOR = 1 };
+int qs_set_rollout_layout(QsEnv *env, int32_t layout);
+
 /* qs_runner_rollout with the networks on the bf16 matrix rate and split (hi + lo) operands, as qs_policy_rollout_fast:
  * about 1e-5 error on means and values instead of float32's 1e-7; opt-in.  packed_weights: device image of
  * qs_runner_rollout_fast_blob_bytes() bytes, 16-byte aligned (layout: quadsim_amd/csrc/policy_rollout.hpp "Fast

@@ -29,7 +29,7 @@ EXPORTS = [
     "qs_runner_rollout", "qs_runner_rollout_fast", "qs_runner_rollout_fast_blob_bytes",
     "qs_step_ex", "qs_set_groups", "qs_group_count", "qs_group_range", "qs_group_stream", "qs_group_set_stream",
     "qs_step_group", "qs_step_groups", "qs_groups_fork", "qs_groups_join",
-    "qs_swap_and_flatten_u8", "qs_gae_flatten", "qs_episode_stats",
+    "qs_swap_and_flatten_u8", "qs_gae_flatten", "qs_episode_stats", "qs_set_rollout_layout",
 ]
 
 
@@ -151,6 +151,7 @@ def load():
         "qs_swap_and_flatten_u8": [vp, i64, i64, vp, vp],
         "qs_gae_flatten": [vp, i64, i64, vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp],
         "qs_episode_stats": [vp, i64, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp],
+        "qs_set_rollout_layout": [vp, i32],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

@@ -40,6 +40,23 @@
 
 using namespace qs;
 
+// -DQS_STAMP (diagnostic build, tools/build_stamp.sh): every workgroup of the role-split step kernel records the
+// 100 MHz real-time counter at its phase boundaries into a caller-provided buffer (qs_debug_set_stamps), keyed by
+// (step counter, tile) -- the in-kernel timeline of consecutive launches of the real chain.  Never in the product build.
+#ifdef QS_STAMP
+__device__ unsigned long long *g_qs_stamps = nullptr;
+__device__ unsigned long long g_qs_stamp_cap = 0;
+#define QS_STAMP_AT(slot)                                                                                      \
+    do {                                                                                                       \
+        if (lane == 0 && g_qs_stamps) {                                                                        \
+            const unsigned long long ix_ = ((k0 % 64ull) * (unsigned long long)(A.tile_end) + (unsigned long long)tile) * 16ull + (slot) + 8 * role; \
+            if (ix_ < g_qs_stamp_cap) g_qs_stamps[ix_] = __builtin_amdgcn_s_memrealtime();                      \
+        }                                                                                                      \
+    } while (0)
+#else
+#define QS_STAMP_AT(slot) ((void)0)
+#endif
+
 namespace {
 
 #ifndef QS_BLOCK
@@ -263,6 +280,7 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
     const int64_t io = env - A.io_env0;          // row of this env in the I/O arrays
     QS_ASSERT(tile < A.tile_end && (!active || (io >= 0 && io < A.io_n)));
     const uint64_t k0 = step_counter_begin(A, tile);
+    QS_STAMP_AT(0);
     const float *b = A.st + tile * (int64_t)(kRecWords * kTile) + lane;
     float *bw = A.st + tile * (int64_t)(kRecWords * kTile) + lane;
     Par P = A.par_nom;
@@ -279,6 +297,10 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
 #pragma unroll
         for (int i = 0; i < 4; ++i) uc[i] = b[(F_UC + i) * kTile];
         float ls = b[F_LS * kTile], tt = b[F_T * kTile];
+#ifdef QS_STAMP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        QS_STAMP_AT(1);
 #pragma clang loop unroll(disable)
         for (int64_t t = 0; t < A.T; ++t) {
             const uint64_t k = k0 + (uint64_t)t;
@@ -295,7 +317,9 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
             float u_c[4];
             chaser_command(a, P.m, u_c);
             const bool lim_c = drone_step<INTEG>(sc, uc, u_c, P, A.C.dt);
+            QS_STAMP_AT(2);
             __syncthreads();                                              // #1: the target's new state is in LDS
+            QS_STAMP_AT(3);
             if (A.T == 1) __builtin_amdgcn_s_setprio(3);                 // single step: from here on this wave is the long pole
             float st[13];
 #pragma unroll
@@ -308,6 +332,7 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
             const bool done = (flags & (FLAG_OVERLIMIT | FLAG_OVERTIME)) != 0;
             const bool rs = done && A.auto_reset;
             s_done[lane] = rs ? 1 : 0;
+            QS_STAMP_AT(4);
             __syncthreads();                                              // #2: reset flags out, this step's Philox words in
             if (rs) {
                 if (A.term_obs && active) store_obs(A.term_obs, io, obs);
@@ -340,6 +365,7 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
                 ls = 0.0f;
                 tt = 0.0f;
             }
+            QS_STAMP_AT(5);
             if (active) {
                 if (A.slab) {
                     float2 *row = reinterpret_cast<float2 *>(A.slab + o * 14);
@@ -364,6 +390,11 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
             if (PARAMS && RMODE == 2) store_par(A.par, tile, lane, P);
         }
         step_counter_end(A, tile, lane, k0);
+        QS_STAMP_AT(6);
+#ifdef QS_STAMP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        QS_STAMP_AT(7);
     } else {
         float st[13], ut[4], qd[4];
 #pragma unroll
@@ -376,6 +407,10 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
         const float vdes[3] = {A.C.vdes_x, 0.0f, 0.0f};
         const float dv[3] = {0.0f, 0.0f, 0.0f};
         if (A.T == 1) __builtin_amdgcn_s_setprio(3);   // single step: the chaser wave waits at #1 for this wave's step + draw
+#ifdef QS_STAMP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        QS_STAMP_AT(1);
 #pragma clang loop unroll(disable)
         for (int64_t t = 0; t < A.T; ++t) {
             const uint64_t k = k0 + (uint64_t)t;
@@ -392,11 +427,13 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
                 s_phx[t & 1][0][lane] = w0;
                 s_phx[t & 1][1][lane] = w1;
             }
+            QS_STAMP_AT(2);
             __syncthreads();                                              // #1
             if (A.T == 1) __builtin_amdgcn_s_setprio(0);
             float u_t[4];
             target_control(A.C.kind, pdes, vdes, qd, 0.0f, pre, dv, P.m, u_t);   // from the state BEFORE stepping
             u_limit(u_t, P.m * kG, ut);
+            QS_STAMP_AT(4);
             __syncthreads();                                              // #2
             if (s_done[lane]) {
                 if (A.term_state && active) {
@@ -552,6 +589,7 @@ struct RunnerArgs {
     float *last_obs;           // nullable [N,12]
     float *last_values;        // [N]
     uint8_t *last_dones;       // [N]
+    int env_major;             // mb_obs / mb_actions rows at env*T + t (already swap_and_flatten-ed) instead of t*N + env
 };
 
 // FAST: the networks on the bf16 matrix rate with split operands (mlp_actor_critic_fast; R.blob = host-packed image)
@@ -610,7 +648,10 @@ __global__ __launch_bounds__(kBlock, 1) void k_runner_rollout(StepArgs A, Runner
     for (int64_t t = 0; t < A.T; ++t) {
         const int64_t o = t * A.n + env;
         QS_ASSERT(!active || (o >= 0 && o < A.T * A.n));
-        if (active) store_obs(A.obs, o, obs);                         // mb_obs: the observation the policy acts on
+        // the two wide arrays can be written env-major right away (ppo2.py:522-523 flattens them afterwards anyway): a
+        // lane's consecutive steps then fill consecutive 48- / 16-byte slots of its own row, which the XCD's L2 merges
+        const int64_t ow = R.env_major ? env * A.T + t : o;
+        if (active) store_obs(A.obs, ow, obs);                        // mb_obs: the observation the policy acts on
         float head[5];
         if (FAST) mlp_actor_critic_fast(obs, head, lds_raw, stage, lane);
         else mlp_actor_critic(obs, head, L, stage, lane);
@@ -641,7 +682,7 @@ __global__ __launch_bounds__(kBlock, 1) void k_runner_rollout(StepArgs A, Runner
             for (int i = 0; i < 4; ++i) a[i] = fminf(fmaxf(u[i], -1.0f), 1.0f);   // ppo2.py:483
         }
         if (active) {
-            reinterpret_cast<float4 *>(R.actions)[o] = make_float4(u[0], u[1], u[2], u[3]);
+            reinterpret_cast<float4 *>(R.actions)[ow] = make_float4(u[0], u[1], u[2], u[3]);
             R.values[o] = head[4];
             R.neglogp[o] = nl;
             A.done[o] = done_prev ? 1 : 0;                            // mb_dones: flags before the step (ppo2.py:479)
@@ -1057,6 +1098,7 @@ struct QsEnv {
     hipEvent_t fork_ev = nullptr;
     bool main_dirty = true;     // the handle enqueued work on its main stream that the group streams have not been ordered behind
     bool groups_dirty = false;  // group streams hold work the main stream has not been ordered behind
+    bool runner_env_major = false;   // qs_set_rollout_layout
 };
 
 namespace {
@@ -1378,6 +1420,17 @@ int do_reset(QsEnv *e, const uint8_t *d_mask, float *d_obs, int init_all)
 extern "C" {
 
 int qs_version(void) { return QS_VERSION; }
+
+#ifdef QS_STAMP
+int qs_debug_set_stamps(void *dev_ptr, uint64_t capacity_words)
+{
+    unsigned long long *p = (unsigned long long *)dev_ptr;
+    unsigned long long c = capacity_words;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_qs_stamps), &p, sizeof p) != hipSuccess) return QS_ERR_HIP;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_qs_stamp_cap), &c, sizeof c) != hipSuccess) return QS_ERR_HIP;
+    return QS_OK;
+}
+#endif
 const char *qs_last_error(void) { return g_err; }
 
 int qs_config_default(QsConfig *cfg)
@@ -2184,6 +2237,7 @@ static int runner_launch(QsEnv *e, const char *who, int64_t T, const float logst
     R.noise = noise; R.dones_in = dones_in;
     R.actions = mb_actions; R.values = mb_values; R.neglogp = mb_neglogp;
     R.last_obs = last_obs; R.last_values = last_values; R.last_dones = last_dones;
+    R.env_major = e->runner_env_major ? 1 : 0;
     const unsigned grid = grid_tiles(e->n);
     const bool fr = e->cfg.integrator == QS_INTEG_FROZEN;
     const int rm = e->cfg.randomise;
@@ -2232,6 +2286,14 @@ int qs_runner_rollout_fast(QsEnv *e, int64_t T, const void *packed_weights, cons
 }
 
 int qs_runner_rollout_fast_blob_bytes(void) { return kAcFastBlobBytes; }
+
+int qs_set_rollout_layout(QsEnv *e, int32_t layout)
+{
+    CHECK_ENV(e);
+    if (layout != QS_LAYOUT_TIME_MAJOR && layout != QS_LAYOUT_ENV_MAJOR) return fail(QS_ERR_INVALID, "qs_set_rollout_layout: unknown layout %d", layout);
+    e->runner_env_major = layout == QS_LAYOUT_ENV_MAJOR;
+    return QS_OK;
+}
 
 int qs_expert_action(QsEnv *e, float *state_des, float kp, float kd, float *actions)
 {

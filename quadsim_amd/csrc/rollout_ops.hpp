@@ -182,23 +182,54 @@ struct GaeFlatArgs {
     float gamma, lam;
 };
 
+// per-wave LDS staging of one 64-env x 16-step block: written one env row per lane, read back so that FOUR lanes cover the
+// 16 consecutive steps of one env -- a store instruction then writes 16 runs of 64 contiguous bytes instead of 64 runs of 16
+constexpr int kGfStride = kGaeGroup + 1;
+
+__device__ __forceinline__ void gf_emit_f32(float *__restrict__ stage, const float x[kGaeGroup], float *__restrict__ out,
+                                            int64_t tile_env0, int64_t t_lo, int64_t T, int64_t N, int lane)
+{
+    // x[j] belongs to step t_lo + (kGaeGroup - 1 - j)
+#pragma unroll
+    for (int j = 0; j < kGaeGroup; ++j) stage[lane * kGfStride + (kGaeGroup - 1 - j)] = x[j];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    const int q = lane & 3;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int e = (lane >> 2) + 16 * p;
+        const float *src = stage + e * kGfStride + 4 * q;
+        const float4 v = make_float4(src[0], src[1], src[2], src[3]);
+        const int64_t env = tile_env0 + e;
+        if (env < N) *reinterpret_cast<float4 *>(out + env * T + t_lo + 4 * q) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+
 __global__ __launch_bounds__(256) void k_gae_flatten(GaeFlatArgs G)
 {
+    __shared__ float s_stage[4][64 * kGfStride];
+    __shared__ uint8_t s_mask[4][64 * (kGaeGroup + 4)];
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= G.N) return;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int64_t tile_env0 = i - lane;
+    const bool active = i < G.N;
+    const int64_t ii = active ? i : 0;           // idle lanes of the tail wave walk env 0 and store nothing
+    float *stage = s_stage[w];
+    uint8_t *mstage = s_mask[w];
     float A = 0.0f;
-    float nextv = G.last_values[i];
-    float nonterm = G.last_dones[i] ? 0.0f : 1.0f;
+    float nextv = G.last_values[ii];
+    float nonterm = G.last_dones[ii] ? 0.0f : 1.0f;
     int64_t t = G.T - 1;
     const float gl = G.gamma * G.lam;
     const bool vec = (G.T & 3) == 0;                         // env-major rows are 16-B aligned
-    const int64_t row = i * G.T;
+    const int64_t row = ii * G.T;
     for (; t >= kGaeGroup - 1; t -= kGaeGroup) {
         float r[kGaeGroup], v[kGaeGroup], nl[kGaeGroup], ret[kGaeGroup];
         uint8_t d[kGaeGroup];
 #pragma unroll
         for (int j = 0; j < kGaeGroup; ++j) {
-            const int64_t o = (t - j) * G.N + i;
+            const int64_t o = (t - j) * G.N + ii;
             QS_ASSERT(o >= 0 && o < G.T * G.N);
             r[j] = G.rewards[o]; v[j] = G.values[o]; d[j] = G.dones[o];
             nl[j] = G.neglogp ? G.neglogp[o] : 0.0f;
@@ -208,24 +239,32 @@ __global__ __launch_bounds__(256) void k_gae_flatten(GaeFlatArgs G)
             const float delta = r[j] + (G.gamma * nextv) * nonterm - v[j];
             A = fmaf(gl * nonterm, A, delta);
             ret[j] = A + v[j];
-            if (G.advs) { const int64_t o = (t - j) * G.N + i; G.advs[o] = A; G.returns[o] = ret[j]; }
+            if (G.advs && active) { const int64_t o = (t - j) * G.N + ii; G.advs[o] = A; G.returns[o] = ret[j]; }
             nextv = v[j];
             nonterm = d[j] ? 0.0f : 1.0f;
         }
         // element j belongs to step t - j: the group covers steps [t-15, t] -> env-major offsets row + t-15 .. row + t
-        const int64_t b = row + t - (kGaeGroup - 1);
-        QS_ASSERT(b >= 0 && b + kGaeGroup <= G.N * G.T);
+        const int64_t t_lo = t - (kGaeGroup - 1);
+        QS_ASSERT(row + t_lo >= 0 && row + t_lo + kGaeGroup <= G.N * G.T);
         if (vec) {
+            gf_emit_f32(stage, ret, G.f_returns, tile_env0, t_lo, G.T, G.N, lane);
+            gf_emit_f32(stage, v, G.f_values, tile_env0, t_lo, G.T, G.N, lane);
+            gf_emit_f32(stage, r, G.f_rewards, tile_env0, t_lo, G.T, G.N, lane);
+            if (G.f_neglogp) gf_emit_f32(stage, nl, G.f_neglogp, tile_env0, t_lo, G.T, G.N, lane);
 #pragma unroll
-            for (int q = 0; q < kGaeGroup / 4; ++q) {
-                const int j0 = kGaeGroup - 1 - 4 * q;         // step b + 4q is element j0
-                reinterpret_cast<float4 *>(G.f_returns + b)[q] = make_float4(ret[j0], ret[j0 - 1], ret[j0 - 2], ret[j0 - 3]);
-                reinterpret_cast<float4 *>(G.f_values + b)[q] = make_float4(v[j0], v[j0 - 1], v[j0 - 2], v[j0 - 3]);
-                reinterpret_cast<float4 *>(G.f_rewards + b)[q] = make_float4(r[j0], r[j0 - 1], r[j0 - 2], r[j0 - 3]);
-                if (G.f_neglogp) reinterpret_cast<float4 *>(G.f_neglogp + b)[q] = make_float4(nl[j0], nl[j0 - 1], nl[j0 - 2], nl[j0 - 3]);
-                reinterpret_cast<uchar4 *>(G.f_masks + b)[q] = make_uchar4(d[j0] ? 1 : 0, d[j0 - 1] ? 1 : 0, d[j0 - 2] ? 1 : 0, d[j0 - 3] ? 1 : 0);
+            for (int j = 0; j < kGaeGroup; ++j) mstage[lane * (kGaeGroup + 4) + (kGaeGroup - 1 - j)] = d[j] ? 1 : 0;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const int q = lane & 3;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int e = (lane >> 2) + 16 * p;
+                const uchar4 m = *reinterpret_cast<const uchar4 *>(mstage + e * (kGaeGroup + 4) + 4 * q);
+                const int64_t env = tile_env0 + e;
+                if (env < G.N) *reinterpret_cast<uchar4 *>(G.f_masks + env * G.T + t_lo + 4 * q) = m;
             }
-        } else {
+            __builtin_amdgcn_wave_barrier();
+        } else if (active) {
 #pragma unroll
             for (int j = 0; j < kGaeGroup; ++j) {
                 const int64_t o = row + t - j;
@@ -235,6 +274,7 @@ __global__ __launch_bounds__(256) void k_gae_flatten(GaeFlatArgs G)
             }
         }
     }
+    if (!active) return;
     for (; t >= 0; --t) {
         const int64_t o = t * G.N + i;
         const float r = G.rewards[o], v = G.values[o];
@@ -263,7 +303,7 @@ struct EpisodeArgs {
     const uint8_t *dones, *last_dones; // [T,N] flags before each step, [N] flags after the last one
     float *ep_ret;                     // [N] in/out: return of the unfinished episode
     int32_t *ep_len;                   // [N] in/out
-    unsigned long long *count;         // device counter (zeroed by the caller): episodes appended so far
+    unsigned long long *count;         // device counter (zeroed by qs_episode_stats before the launch): episodes appended
     int64_t *out_key;                  // [cap]
     float *out_ret;                    // [cap]
     int32_t *out_len;                  // [cap]
@@ -275,6 +315,8 @@ __device__ __forceinline__ bool ep_done_after(const EpisodeArgs &E, int64_t t, i
     return (t + 1 < E.T ? E.dones[(t + 1) * E.N + i] : E.last_dones[i]) != 0;
 }
 
+constexpr int kEpGroup = 16;   // steps whose loads are in flight together (a lone wave per SIMD is latency-bound otherwise)
+
 __global__ __launch_bounds__(256) void k_episode_stats(EpisodeArgs E)
 {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -283,7 +325,16 @@ __global__ __launch_bounds__(256) void k_episode_stats(EpisodeArgs E)
     const int lane = threadIdx.x & 63;
     // pass 1: episodes ending in this lane's env, then in this wave
     unsigned mine = 0;
-    for (int64_t t = 0; t < E.T; ++t) mine += (active && ep_done_after(E, t, ii)) ? 1u : 0u;
+    int64_t t = 0;
+    for (; t + kEpGroup <= E.T; t += kEpGroup) {
+        uint8_t d[kEpGroup];
+#pragma unroll
+        for (int j = 0; j < kEpGroup; ++j) d[j] = (t + j + 1 < E.T ? E.dones[(t + j + 1) * E.N + ii] : E.last_dones[ii]);
+#pragma unroll
+        for (int j = 0; j < kEpGroup; ++j) mine += d[j] ? 1u : 0u;
+    }
+    for (; t < E.T; ++t) mine += ep_done_after(E, t, ii) ? 1u : 0u;
+    if (!active) mine = 0;
     unsigned total = mine;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) total += __shfl_xor(total, off, 64);
@@ -294,23 +345,35 @@ __global__ __launch_bounds__(256) void k_episode_stats(EpisodeArgs E)
     float ret = active ? E.ep_ret[ii] : 0.0f;
     int32_t len = active ? E.ep_len[ii] : 0;
     unsigned long long next = base;
-    for (int64_t t = 0; t < E.T; ++t) {
-        const float r = active ? E.rewards[t * E.N + ii] : 0.0f;
+    auto one = [&](int64_t tt, float r, bool d) {
         ret += r;
         len += 1;
-        const bool d = active && ep_done_after(E, t, ii);
+        d = d && active;
         const unsigned long long bal = __ballot(d);
         if (bal) {
             if (d) {
                 const unsigned long long slot = next + (unsigned long long)__popcll(bal & ((1ull << lane) - 1ull));
                 QS_ASSERT(slot < base + total);
-                if ((int64_t)slot < E.cap) { E.out_key[slot] = t * E.N + ii; E.out_ret[slot] = ret; E.out_len[slot] = len; }
+                if ((int64_t)slot < E.cap) { E.out_key[slot] = tt * E.N + ii; E.out_ret[slot] = ret; E.out_len[slot] = len; }
                 ret = 0.0f;
                 len = 0;
             }
             next += (unsigned long long)__popcll(bal);
         }
+    };
+    t = 0;
+    for (; t + kEpGroup <= E.T; t += kEpGroup) {
+        uint8_t d[kEpGroup];
+        float r[kEpGroup];
+#pragma unroll
+        for (int j = 0; j < kEpGroup; ++j) {
+            d[j] = (t + j + 1 < E.T ? E.dones[(t + j + 1) * E.N + ii] : E.last_dones[ii]);
+            r[j] = E.rewards[(t + j) * E.N + ii];
+        }
+#pragma unroll
+        for (int j = 0; j < kEpGroup; ++j) one(t + j, r[j], d[j] != 0);
     }
+    for (; t < E.T; ++t) one(t, E.rewards[t * E.N + ii], ep_done_after(E, t, ii));
     if (active) { E.ep_ret[ii] = ret; E.ep_len[ii] = len; }
 }
 

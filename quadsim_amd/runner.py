@@ -128,18 +128,21 @@ def pack_fast_actor_critic(policy):
     return np.frombuffer(b"".join(parts), np.uint8)
 
 
-def fused_runner_rollout(env, policy, T, noise=None, dones_in=None, want_flags=False, precision="f32"):
+def fused_runner_rollout(env, policy, T, noise=None, dones_in=None, want_flags=False, precision="f32", env_major=False):
     """qs_runner_rollout: T Runner steps for all envs in one launch, from the envs' current state.
     -> dict of device tensors: obs [T,N,12] (the observations acted on), actions [T,N,4] (un-clipped samples),
     values, neglogp, rewards [T,N] f32, dones [T,N] u8 (flags BEFORE each step), flags [T,N] u8 or None,
     last_obs [N,12], last_values [N], last_dones [N] u8.
     precision "f32": exact-float32 MFMA; "bf16x3": qs_runner_rollout_fast, split-bf16 operands on the bf16 matrix
-    rate, ~1e-5 error on means / values (opt-in)."""
+    rate, ~1e-5 error on means / values (opt-in).
+    env_major: obs / actions come out as [N,T,12] / [N,T,4] (what swap_and_flatten would make of them); the [T,N]
+    scalars are unaffected."""
     import torch
     n, dev = env.num_envs, env.device
     f32, u8 = torch.float32, torch.uint8
     out = {
-        "obs": torch.empty((T, n, 12), dtype=f32, device=dev), "actions": torch.empty((T, n, 4), dtype=f32, device=dev),
+        "obs": torch.empty((n, T, 12) if env_major else (T, n, 12), dtype=f32, device=dev),
+        "actions": torch.empty((n, T, 4) if env_major else (T, n, 4), dtype=f32, device=dev),
         "values": torch.empty((T, n), dtype=f32, device=dev), "neglogp": torch.empty((T, n), dtype=f32, device=dev),
         "dones": torch.empty((T, n), dtype=u8, device=dev), "rewards": torch.empty((T, n), dtype=f32, device=dev),
         "flags": torch.empty((T, n), dtype=u8, device=dev) if want_flags else None,
@@ -154,6 +157,8 @@ def fused_runner_rollout(env, policy, T, noise=None, dones_in=None, want_flags=F
         dones_in = dones_in.to(device=dev).to(u8).contiguous()
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None      # noqa: E731
     env._use_current_stream()
+    env._inputs_ready()
+    _lib.check(env._lib.qs_set_rollout_layout(env._h, 1 if env_major else 0), "qs_set_rollout_layout")
     tail = (p(noise), p(dones_in), p(out["obs"]), p(out["actions"]), p(out["values"]), p(out["neglogp"]), p(out["dones"]),
             p(out["rewards"]), p(out["flags"]), p(out["last_obs"]), p(out["last_values"]), p(out["last_dones"]))
     if precision == "f32":
@@ -169,6 +174,7 @@ def fused_runner_rollout(env, policy, T, noise=None, dones_in=None, want_flags=F
                    "qs_runner_rollout_fast")
     else:
         raise ValueError("precision must be 'f32' or 'bf16x3'")
+    env._outputs_ready()
     return out
 
 
@@ -251,9 +257,13 @@ class Runner:
         env, T = self.env, self.n_steps
         mb_states = self.states
         if self.fused:
-            ro = fused_runner_rollout(env, self.model, T, noise=noise, dones_in=self.dones, precision=self.precision)
+            # obs / actions leave the kernel env-major: no transpose pass over the two wide arrays
+            ro = fused_runner_rollout(env, self.model, T, noise=noise, dones_in=self.dones, precision=self.precision,
+                                      env_major=True)
+            flat_obs, flat_actions = ro["obs"].view(T * env.num_envs, 12), ro["actions"].view(T * env.num_envs, 4)
         else:
             ro = self._stepwise_rollout(noise)
+            flat_obs, flat_actions = swap_and_flatten(env, ro["obs"]), swap_and_flatten(env, ro["actions"])
         self.num_timesteps += T * env.num_envs
         # ppo2.py:507-523 in one pass: GAE + the env-major flatten of returns / dones / values / neglogp / rewards
         gf = gae_and_flatten(env, ro["rewards"], ro["values"], ro["neglogp"], ro["dones"], ro["last_values"],
@@ -262,8 +272,8 @@ class Runner:
         if self.track_episodes:
             ep_infos = self._episode_infos(ro["rewards"], ro["dones"], ro["last_dones"])
         self.obs, self.dones = ro["last_obs"], ro["last_dones"]
-        out = (swap_and_flatten(env, ro["obs"]), gf["returns"], gf["masks"], swap_and_flatten(env, ro["actions"]),
-               gf["values"], gf["neglogp"], mb_states, ep_infos, gf["rewards"])
+        out = (flat_obs, gf["returns"], gf["masks"], flat_actions, gf["values"], gf["neglogp"], mb_states, ep_infos,
+               gf["rewards"])
         if self.reset_after_run:
             self.obs = env.reset()                                                         # ppo2.py:525
         return out
