@@ -148,9 +148,24 @@ def cpu_baseline(kind, seconds, seed=1234):
     with ThreadPoolExecutor(cores) as ex:
         total = sum(ex.map(worker, range(cores)))
     dt = time.perf_counter() - t0
-    return {"value": total / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": "C oracle (f64 restatement of the reference path), %d threads x 1024 envs, U(-1,1) actions, "
-                      "randomised auto-reset, %.1f s wall" % (cores, dt)}
+    out = {"value": total / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+           "sample": "C oracle (f64 restatement of the reference path), %d threads x 1024 envs, U(-1,1) actions, "
+                     "randomised auto-reset, %.1f s wall" % (cores, dt)}
+    # the NumPy twin (oracle/np_oracle.py: the same closed form as array code), one process, 4 096 envs per call
+    import warnings
+    from oracle import np_oracle
+    rec = orc.env_init(4096)
+    a4 = rs.uniform(-1, 1, (4096, 4))
+    k, t0 = 0, time.perf_counter()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        while time.perf_counter() - t0 < 2.0:
+            rec2, _, _, d, _ = np_oracle.env_step(rec, a4, kind=kind)
+            rec = np.where(d[:, None], rec, rec2)            # finished envs restart from the nominal record
+            k += 1
+    out["numpy_twin"] = {"value": k * 4096 / (time.perf_counter() - t0), "unit": "env-steps/s", "cores": 1,
+                         "what": "oracle/np_oracle.py, float64, 4 096 envs per vectorised call"}
+    return out
 
 
 def config1_cpu(seconds=2.0):

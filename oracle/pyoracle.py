@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "libqso.so")
+LIB_PATH = os.environ.get("QSO_LIB") or os.path.join(HERE, "libqso.so")   # override: the sanitizer build (make asan)
 
 REC_LEN = 40
 REC_SC, REC_ST, REC_UC, REC_UT, REC_QD, REC_LS, REC_T = 0, 13, 26, 30, 34, 38, 39
@@ -26,6 +26,8 @@ RR_NONE = (0.0, 0.0, 0.0, 0.0, 1.0, 1.0, 1.0, 1.0)
 def build(force=False):
     """Compile libqso.so with gcc (make -C oracle)."""
     src = os.path.join(HERE, "quadsim_oracle.c")
+    if os.environ.get("QSO_LIB"):
+        return LIB_PATH
     if (not force and os.path.exists(LIB_PATH)
             and os.path.getmtime(LIB_PATH) >= os.path.getmtime(src)):
         return LIB_PATH

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <dlfcn.h>
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
@@ -1054,6 +1055,37 @@ int fail(int code, const char *fmt, ...)
         if (e_ != hipSuccess) return fail(QS_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
+// roctx ranges around the hot entry points (trace readability under rocprofv3 --marker-trace): resolved at run time and
+// only when QS_ROCTX=1, so the library carries no link-time dependency on a profiler library
+struct Roctx {
+    int (*push)(const char *) = nullptr;
+    int (*pop)() = nullptr;
+    bool on = false;
+};
+inline Roctx &roctx()
+{
+    static Roctx r = [] {
+        Roctx x;
+        const char *en = getenv("QS_ROCTX");
+        if (en && atoi(en)) {
+            void *h = dlopen("librocprofiler-sdk-roctx.so", RTLD_NOW | RTLD_GLOBAL);
+            if (!h) h = dlopen("libroctx64.so", RTLD_NOW | RTLD_GLOBAL);
+            if (h) {
+                x.push = (int (*)(const char *))dlsym(h, "roctxRangePushA");
+                x.pop = (int (*)())dlsym(h, "roctxRangePop");
+                x.on = x.push && x.pop;
+            }
+        }
+        return x;
+    }();
+    return r;
+}
+struct Range {
+    bool on;
+    explicit Range(const char *name) : on(roctx().on) { if (on) roctx().push(name); }
+    ~Range() { if (on) roctx().pop(); }
+};
+
 struct DeviceGuard {
     int prev = -1;
     bool ok = true;
@@ -1130,6 +1162,7 @@ StepArgs make_args(const QsEnv *e)
     A.par_nom = Par{e->cfg.mass, e->cfg.inertia[0], e->cfg.inertia[1], e->cfg.inertia[2]};
     A.auto_reset = e->cfg.auto_reset;
     A.randomise = e->cfg.randomise;
+
     for (int i = 0; i < 12; ++i) A.nominal_obs[i] = e->nominal_obs[i];
     return A;
 }
@@ -1613,6 +1646,7 @@ int qs_set_step_counter(QsEnv *e, uint64_t k)
 
 int qs_reset(QsEnv *e, const uint8_t *mask, float *obs_out)
 {
+    Range rg_("qs_reset");
     CHECK_ENV(e);
     const int64_t n = e->n;
     if (e->cfg.io_space == QS_IO_DEVICE) return do_reset(e, mask, obs_out, 0);
@@ -1641,6 +1675,7 @@ int qs_reset(QsEnv *e, const uint8_t *mask, float *obs_out)
 int qs_step_ex(QsEnv *e, const float *actions, float *obs, float *reward, uint8_t *done, uint8_t *flags, float *terminal_obs,
                float *terminal_state)
 {
+    Range rg_("qs_step_ex");
     CHECK_ENV(e);
     if (!actions || !obs || !reward || !done) return fail(QS_ERR_INVALID, "qs_step: actions, obs, reward and done are required");
     if (terminal_state && e->cfg.kind == QS_KIND_HOVERING_V0)
@@ -1801,6 +1836,7 @@ static int step_group_post(QsEnv *e, QsGroup *G, const float *actions, float *ob
 int qs_step_group(QsEnv *e, int32_t g, const float *actions, float *obs, float *reward, uint8_t *done, uint8_t *flags,
                   float *terminal_obs, float *terminal_state)
 {
+    Range rg_("qs_step_group");
     CHECK_ENV_RAW(e);
     if (g < 0 || g >= (int32_t)e->groups.size()) return fail(QS_ERR_INVALID, "qs_step_group: group %d out of range (qs_set_groups first)", g);
     if (!actions || !obs || !reward || !done) return fail(QS_ERR_INVALID, "qs_step_group: actions, obs, reward and done are required");
@@ -1813,6 +1849,7 @@ int qs_step_group(QsEnv *e, int32_t g, const float *actions, float *obs, float *
 int qs_step_groups(QsEnv *e, const float *actions, float *obs, float *reward, uint8_t *done, uint8_t *flags, float *terminal_obs,
                    float *terminal_state)
 {
+    Range rg_("qs_step_groups");
     CHECK_ENV_RAW(e);
     if (e->groups.empty()) return qs_step_ex(e, actions, obs, reward, done, flags, terminal_obs, terminal_state);
     if (!actions || !obs || !reward || !done) return fail(QS_ERR_INVALID, "qs_step_groups: actions, obs, reward and done are required");
@@ -1828,6 +1865,7 @@ int qs_step_groups(QsEnv *e, const float *actions, float *obs, float *reward, ui
 
 int qs_rollout(QsEnv *e, int64_t T, const float *actions, float *obs, float *reward, uint8_t *done, uint8_t *flags)
 {
+    Range rg_("qs_rollout");
     CHECK_ENV(e);
     if (T < 1) return fail(QS_ERR_INVALID, "qs_rollout: T must be >= 1");
     if (!obs || !reward || !done) return fail(QS_ERR_INVALID, "qs_rollout: obs, reward and done are required");
@@ -1862,6 +1900,7 @@ int qs_rollout(QsEnv *e, int64_t T, const float *actions, float *obs, float *rew
 
 int qs_rollout_slab(QsEnv *e, int64_t T, const float *actions, float *slab, uint8_t *flags)
 {
+    Range rg_("qs_rollout_slab");
     CHECK_ENV(e);
     if (T < 1 || !slab) return fail(QS_ERR_INVALID, "qs_rollout_slab: bad arguments");
     if (!e->cfg.auto_reset) return fail(QS_ERR_INVALID, "qs_rollout_slab: requires auto_reset");
@@ -1874,6 +1913,7 @@ int qs_rollout_slab(QsEnv *e, int64_t T, const float *actions, float *slab, uint
 
 int qs_rollout_stepwise(QsEnv *e, int64_t T, const float *actions, float *obs, float *reward, uint8_t *done, uint8_t *flags)
 {
+    Range rg_("qs_rollout_stepwise");
     CHECK_ENV(e);
     if (T < 1 || !actions || !obs || !reward || !done) return fail(QS_ERR_INVALID, "qs_rollout_stepwise: bad arguments");
     if (!e->cfg.auto_reset) return fail(QS_ERR_INVALID, "qs_rollout_stepwise: requires auto_reset");
@@ -2059,6 +2099,7 @@ int qs_get_init_state(QsEnv *e, float *chaser_init, float *target_init)
 int qs_gae(QsEnv *e, int64_t T, int64_t n, const float *rewards, const float *values, const uint8_t *dones,
            const float *last_values, const uint8_t *last_dones, float gamma, float lam, float *advs, float *returns)
 {
+    Range rg_("qs_gae");
     CHECK_ENV(e);
     if (T < 1 || n < 1 || !rewards || !values || !dones || !last_values || !last_dones || !advs || !returns)
         return fail(QS_ERR_INVALID, "qs_gae: bad arguments");
@@ -2093,6 +2134,7 @@ int qs_gae(QsEnv *e, int64_t T, int64_t n, const float *rewards, const float *va
 
 int qs_swap_and_flatten(QsEnv *e, int64_t T, int64_t n, int64_t d, const float *in, float *out)
 {
+    Range rg_("qs_swap_and_flatten");
     CHECK_ENV(e);
     if (T < 1 || n < 1 || !in || !out) return fail(QS_ERR_INVALID, "qs_swap_and_flatten: bad arguments");
     if (e->cfg.io_space != QS_IO_DEVICE) return fail(QS_ERR_INVALID, "qs_swap_and_flatten: device buffers only");
@@ -2124,6 +2166,7 @@ int qs_gae_flatten(QsEnv *e, int64_t T, int64_t n, const float *rewards, const f
                    float *flat_returns, float *flat_values, float *flat_neglogp, float *flat_rewards, uint8_t *flat_masks,
                    float *advs, float *returns)
 {
+    Range rg_("qs_gae_flatten");
     CHECK_ENV(e);
     if (T < 1 || n < 1 || !rewards || !values || !dones || !last_values || !last_dones || !flat_returns || !flat_values ||
         !flat_rewards || !flat_masks)
@@ -2145,6 +2188,7 @@ int qs_gae_flatten(QsEnv *e, int64_t T, int64_t n, const float *rewards, const f
 int qs_episode_stats(QsEnv *e, int64_t T, int64_t n, const float *rewards, const uint8_t *dones, const uint8_t *last_dones,
                      float *ep_ret, int32_t *ep_len, uint64_t *count, int64_t cap, int64_t *out_key, float *out_ret, int32_t *out_len)
 {
+    Range rg_("qs_episode_stats");
     CHECK_ENV(e);
     if (T < 1 || n < 1 || cap < 0 || !rewards || !dones || !last_dones || !ep_ret || !ep_len || !count || (cap > 0 && (!out_key || !out_ret || !out_len)))
         return fail(QS_ERR_INVALID, "qs_episode_stats: bad arguments");
@@ -2162,6 +2206,7 @@ int qs_episode_stats(QsEnv *e, int64_t T, int64_t n, const float *rewards, const
 int qs_policy_rollout(QsEnv *e, int64_t T, const float *wt1, const float *b1, const float *wt2, const float *b2,
                       const float *wt3, const float *b3, float *obs, float *reward, uint8_t *done, uint8_t *flags, float *actions)
 {
+    Range rg_("qs_policy_rollout");
     CHECK_ENV(e);
     if (T < 1 || !wt1 || !b1 || !wt2 || !b2 || !wt3 || !b3 || !obs || !reward || !done)
         return fail(QS_ERR_INVALID, "qs_policy_rollout: bad arguments");
@@ -2186,6 +2231,7 @@ int qs_policy_rollout(QsEnv *e, int64_t T, const float *wt1, const float *b1, co
 int qs_policy_rollout_fast(QsEnv *e, int64_t T, const void *packed_weights, float *obs, float *reward, uint8_t *done,
                            uint8_t *flags, float *actions)
 {
+    Range rg_("qs_policy_rollout_fast");
     CHECK_ENV(e);
     if (T < 1 || !packed_weights || !obs || !reward || !done) return fail(QS_ERR_INVALID, "qs_policy_rollout_fast: bad arguments");
     if (e->cfg.io_space != QS_IO_DEVICE) return fail(QS_ERR_INVALID, "qs_policy_rollout_fast: device buffers only");
@@ -2214,6 +2260,7 @@ static int runner_launch(QsEnv *e, const char *who, int64_t T, const float logst
                          float *mb_values, float *mb_neglogp, uint8_t *mb_dones, float *mb_rewards, uint8_t *mb_flags,
                          float *last_obs, float *last_values, uint8_t *last_dones)
 {
+    Range rg_(who);
     if (T < 1 || !mb_obs || !mb_actions || !mb_values || !mb_neglogp || !mb_dones || !mb_rewards || !last_values || !last_dones)
         return fail(QS_ERR_INVALID, "%s: bad arguments", who);
     if (e->cfg.io_space != QS_IO_DEVICE) return fail(QS_ERR_INVALID, "%s: device buffers only", who);

@@ -4,6 +4,7 @@ layer-1 entry points (qs_drone_step / qs_ctrl, host I/O).  Same names, argument
 meaning and in-place mutation behaviour as the reference so that
 run_sim_PID.py:23-54-style loops read unchanged.
 """
+import atexit
 import ctypes as C
 
 import numpy as np
@@ -11,6 +12,17 @@ import numpy as np
 from . import _lib
 
 _ctx = {}
+
+
+def _close_contexts():
+    """qs_destroy every cached layer-1 handle (registered with atexit; also callable to release the device early)"""
+    lib = _lib.load() if _ctx else None
+    while _ctx:
+        _, h = _ctx.popitem()
+        lib.qs_destroy(h)
+
+
+atexit.register(_close_contexts)
 
 
 def _context(device=0, integrator=_lib.INTEG_FROZEN, dt=0.02, mass=0.18, inertia=(0.00025, 0.000232, 0.0003738)):

@@ -278,3 +278,42 @@ def test_g12_dock_port_state(oracle64):
         pos, vel = oracle64.dock_port(g["state"][i], g["port"][i])
         np.testing.assert_allclose(pos, g["pos"][i], rtol=0, atol=1e-12)
         np.testing.assert_allclose(vel, g["vel"][i], rtol=0, atol=1e-12)
+
+
+@pytest.mark.parametrize("name,kind", [("g4_traj_v0", 0), ("g4_traj_v2", 1), ("g5_policy_episode", 0)])
+def test_numpy_twin_against_reference_fixtures(name, kind):
+    """oracle/np_oracle.py (array restatement of SURVEY.md Appendix A, independent of the C one) on the recorded
+    reference steps: 1e-12 like the C oracle, so either can serve as the checker"""
+    import warnings
+    from oracle import np_oracle
+    g = load_golden(name)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        rec, obs, rew, done, flags = np_oracle.env_step(g["rec_before"], g["actions"], kind=kind)
+    ra = g["rec_after"]
+    np.testing.assert_allclose(rec, ra, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(obs, g["obs"], rtol=1e-11, atol=1e-11)
+    np.testing.assert_allclose(rew, g["reward"], rtol=0, atol=1e-11)
+    assert np.array_equal(done, g["done"].astype(bool))
+    assert np.array_equal(flags & 7, g["flags"])
+
+
+def test_numpy_twin_against_c_oracle_with_params(oracle64):
+    """the two restatements against each other on the domain-randomised fixture (per-env mass / inertia)"""
+    import warnings
+    from oracle import np_oracle
+    g = load_golden("g7_domain_rand")
+    for kind in (0, 1):
+        for j in range(3):
+            key = "k%d_s%d_" % (kind, j)
+            rb, par = g[key + "rec_before"], g[key + "par"]
+            n = len(rb)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                rec, obs, rew, done, flags = np_oracle.env_step(rb, g[key + "actions"], par=np.tile(par, (n, 1)), kind=kind)
+            np.testing.assert_allclose(rec, g[key + "rec_after"], rtol=1e-12, atol=1e-12)
+            for i in range(0, n, 37):
+                r_c, o_c, rew_c, d_c, f_c = oracle64.env_step(rb[i], g[key + "actions"][i], par=par, kind=kind)
+                np.testing.assert_allclose(rec[i], r_c, rtol=1e-12, atol=1e-12)
+                np.testing.assert_allclose(obs[i], o_c, rtol=1e-11, atol=1e-11)
+                assert bool(done[i]) == d_c and int(flags[i]) == f_c
