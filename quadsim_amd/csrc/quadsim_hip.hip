@@ -47,15 +47,20 @@ using namespace qs;
 #ifdef QS_STAMP
 __device__ unsigned long long *g_qs_stamps = nullptr;
 __device__ unsigned long long g_qs_stamp_cap = 0;
-#define QS_STAMP_AT(slot)                                                                                      \
-    do {                                                                                                       \
-        if (lane == 0 && g_qs_stamps) {                                                                        \
-            const unsigned long long ix_ = ((k0 % 64ull) * (unsigned long long)(A.tile_end) + (unsigned long long)tile) * 16ull + (slot) + 8 * role; \
-            if (ix_ < g_qs_stamp_cap) g_qs_stamps[ix_] = __builtin_amdgcn_s_memrealtime();                      \
-        }                                                                                                      \
+// stamps stay in registers until the wave's last instruction: a store next to a barrier would be waited for by it
+#define QS_STAMP_DECL unsigned long long stamp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define QS_STAMP_AT(slot) (stamp_[slot] = __builtin_amdgcn_s_memrealtime())
+#define QS_STAMP_FLUSH()                                                                                        \
+    do {                                                                                                        \
+        if (lane == 0 && g_qs_stamps) {                                                                         \
+            const unsigned long long ix_ = ((k0 % 64ull) * (unsigned long long)(A.tile_end) + (unsigned long long)tile) * 16ull + 8 * role; \
+            if (ix_ + 8 <= g_qs_stamp_cap) for (int j_ = 0; j_ < 8; ++j_) g_qs_stamps[ix_ + j_] = stamp_[j_];    \
+        }                                                                                                       \
     } while (0)
 #else
+#define QS_STAMP_DECL ((void)0)
 #define QS_STAMP_AT(slot) ((void)0)
+#define QS_STAMP_FLUSH() ((void)0)
 #endif
 
 namespace {
@@ -281,6 +286,7 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
     const int64_t io = env - A.io_env0;          // row of this env in the I/O arrays
     QS_ASSERT(tile < A.tile_end && (!active || (io >= 0 && io < A.io_n)));
     const uint64_t k0 = step_counter_begin(A, tile);
+    QS_STAMP_DECL;
     QS_STAMP_AT(0);
     const float *b = A.st + tile * (int64_t)(kRecWords * kTile) + lane;
     float *bw = A.st + tile * (int64_t)(kRecWords * kTile) + lane;
@@ -290,22 +296,27 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
         // in a roll-out the chaser wave is the long pole of every step while target waves on the same SIMD run ahead with
         // speculative draws: give it the issue slots first (roll-out 2.28 -> 2.13 us/step; no help for a single step)
         if (A.T > 1) __builtin_amdgcn_s_setprio(3);
-        float4 av_next = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (A.actions && active) av_next = reinterpret_cast<const float4 *>(A.actions)[io];
         float sc[13], uc[4];
 #pragma unroll
         for (int i = 0; i < 13; ++i) sc[i] = b[(F_SC + i) * kTile];
 #pragma unroll
         for (int i = 0; i < 4; ++i) uc[i] = b[(F_UC + i) * kTile];
         float ls = b[F_LS * kTile], tt = b[F_T * kTile];
+        // the action is requested LAST: loads return in issue order, and the action -- fresh from the caller, the one
+        // operand that is not cache-resident -- is not needed before the integration (which uses the PREVIOUS limited
+        // control, quadrotor.py:126-144) is done; its miss latency hides under drone_advance
+        float4 av_next = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (A.actions && active) av_next = reinterpret_cast<const float4 *>(A.actions)[io];
 #ifdef QS_STAMP
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
 #endif
         QS_STAMP_AT(1);
 #pragma clang loop unroll(disable)
         for (int64_t t = 0; t < A.T; ++t) {
             const uint64_t k = k0 + (uint64_t)t;
             const int64_t o = t * A.io_n + io;
+            tt += 1.0f;
+            const bool lim_c = drone_advance<INTEG>(sc, uc, P, A.C.dt);   // Drone.step's integration: previous control only
             float a[4];
             if (A.actions) {
                 const float4 av = av_next;
@@ -314,10 +325,9 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
             } else {
                 random_action(A.rc.seed, A.gid0 + (uint64_t)env, k, a);
             }
-            tt += 1.0f;
             float u_c[4];
             chaser_command(a, P.m, u_c);
-            const bool lim_c = drone_step<INTEG>(sc, uc, u_c, P, A.C.dt);
+            u_limit(u_c, P.m * kG, uc);                                   // ... and the hand-over of the new limited control
             QS_STAMP_AT(2);
             __syncthreads();                                              // #1: the target's new state is in LDS
             QS_STAMP_AT(3);
@@ -335,6 +345,7 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
             s_done[lane] = rs ? 1 : 0;
             QS_STAMP_AT(4);
             __syncthreads();                                              // #2: reset flags out, this step's Philox words in
+            QS_STAMP_AT(5);
             if (rs) {
                 if (A.term_obs && active) store_obs(A.term_obs, io, obs);
                 if (A.term_state && active) {
@@ -366,7 +377,7 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
                 ls = 0.0f;
                 tt = 0.0f;
             }
-            QS_STAMP_AT(5);
+            QS_STAMP_AT(6);
             if (active) {
                 if (A.slab) {
                     float2 *row = reinterpret_cast<float2 *>(A.slab + o * 14);
@@ -391,11 +402,11 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
             if (PARAMS && RMODE == 2) store_par(A.par, tile, lane, P);
         }
         step_counter_end(A, tile, lane, k0);
-        QS_STAMP_AT(6);
 #ifdef QS_STAMP
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         QS_STAMP_AT(7);
+        QS_STAMP_FLUSH();
     } else {
         float st[13], ut[4], qd[4];
 #pragma unroll
@@ -430,12 +441,14 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
             }
             QS_STAMP_AT(2);
             __syncthreads();                                              // #1
+            QS_STAMP_AT(3);
             if (A.T == 1) __builtin_amdgcn_s_setprio(0);
             float u_t[4];
             target_control(A.C.kind, pdes, vdes, qd, 0.0f, pre, dv, P.m, u_t);   // from the state BEFORE stepping
             u_limit(u_t, P.m * kG, ut);
             QS_STAMP_AT(4);
             __syncthreads();                                              // #2
+            QS_STAMP_AT(5);
             if (s_done[lane]) {
                 if (A.term_state && active) {
                     float *ts = A.term_state + io * 26 + 13;
@@ -469,6 +482,8 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
 #pragma unroll
             for (int i = 0; i < 4; ++i) bw[(F_QD + i) * kTile] = qd[i];
         }
+        QS_STAMP_AT(6);
+        QS_STAMP_FLUSH();
     }
 }
 
