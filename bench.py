@@ -285,6 +285,12 @@ def main():
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(spawn_ranks(args))          # the parent never initialises the GPU
 
+    # stdout carries the ONE JSON line and nothing else: whatever libraries print there while the bench runs (the RCCL
+    # version banner, gloo's connection messages) goes to stderr instead -- fd 1 is pointed at fd 2 until the line is due
+    sys.stdout.flush()
+    saved_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
@@ -430,9 +436,9 @@ def main():
         per_launch_bytes = bpe * n / groups
         out["roofline"].update({"rocprof_kernel_avg_us": avg_us, "rocprof_calls": calls, "rocprof_source": src,
                                 "rocprof_kernel_frac": per_launch_bytes / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                "rocprof_note": "bytes of ONE launch (%d envs) / its average duration under the profiler; with "
-                                                "%d groups in flight the launches overlap, so the step period is shorter than "
-                                                "%d x this" % (n // groups, groups, groups)})
+                                "rocprof_note": "bytes of ONE launch (%d envs) / its average duration in the profiled process "
+                                                "(`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 500 --warmup 50 "
+                                                "--no-extras ...`; the profiler adds a completion signal per dispatch)" % (n // groups)})
     # HBM-side bytes per step from the PMC passes (collected separately: rocprofv3 --pmc cannot run inside
     # this process); only quoted when the profile was taken on this very configuration
     try:
@@ -566,6 +572,9 @@ def main():
     if distributed:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    os.close(saved_stdout)
     if rank == 0:
         print(json.dumps(out), flush=True)
 

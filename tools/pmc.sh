@@ -6,7 +6,7 @@ R=$(pwd); OUT=$R/gpurun_out/pmc_$TAG; mkdir -p $OUT
 export TMPDIR=/tmp; cd /tmp
 for N in 65536 2097152; do
   for C in FETCH_SIZE WRITE_SIZE; do
-    timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $OUT/${C}_$N -- python3 $R/bench.py --envs-per-gpu $N --steps 200 --warmup 20 --action-pool 8 --no-cpu-baseline --no-extras > $OUT/${C}_$N.log 2>&1 || echo "pass $C $N failed"
+    timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $OUT/${C}_$N -- python3 $R/bench.py --envs-per-gpu $N --steps 200 --warmup 20 --action-pool 8 --no-cpu-baseline --no-extras --no-parity > $OUT/${C}_$N.log 2>&1 || echo "pass $C $N failed"
   done
 done
 cd $R
