@@ -67,12 +67,13 @@ __device__ unsigned long long g_qs_stamp_cap = 0;
 // LATER launch (the next step, the policy), never by this one, and each launch ends with the write-back of the L2s' dirty lines:
 // streaming stores leave that write-back less to do (65 536 envs: 6.92 -> 6.60 us per step; 131 072: 9.21 -> 8.87 us; plain
 // stores with -DQS_PLAIN_STORES for A/B).  `sc1` write-through stores, in contrast, evict the lines and cost more than they save.
-#ifdef QS_PLAIN_STORES
+#if defined(QS_PLAIN_STORES)
 #define QS_ST(p, v) (*(p) = (v))
+#define QS_SO(p, v) QS_ST(p, v)
 #else
 #define QS_ST(p, v) __builtin_nontemporal_store((v), (p))
-#endif
 #define QS_SO(p, v) QS_ST(p, v)
+#endif
 
 namespace {
 
@@ -164,9 +165,9 @@ __device__ __forceinline__ void store_obs(float *__restrict__ obs, int64_t env, 
 {
     typedef float f4 __attribute__((ext_vector_type(4)));
     f4 *p = reinterpret_cast<f4 *>(obs + env * 12);
-    QS_ST(&p[0], (f4{o[0], o[1], o[2], o[3]}));
-    QS_ST(&p[1], (f4{o[4], o[5], o[6], o[7]}));
-    QS_ST(&p[2], (f4{o[8], o[9], o[10], o[11]}));
+    QS_SO(&p[0], (f4{o[0], o[1], o[2], o[3]}));
+    QS_SO(&p[1], (f4{o[4], o[5], o[6], o[7]}));
+    QS_SO(&p[2], (f4{o[8], o[9], o[10], o[11]}));
 }
 
 // plain (cached) flavour: rows that are completed by LATER stores of the same lane (the env-major roll-out arrays, where a
@@ -277,10 +278,10 @@ __global__ __launch_bounds__(kBlock) void k_env(StepArgs A)
             row[6] = make_float2(reward, done ? 1.0f : 0.0f);
         } else {
             store_obs(A.obs, o, obs);
-            QS_ST(&A.reward[o], reward);
-            QS_ST(&A.done[o], (uint8_t)(done ? 1 : 0));
+            QS_SO(&A.reward[o], reward);
+            QS_SO(&A.done[o], (uint8_t)(done ? 1 : 0));
         }
-        if (A.flags) QS_ST(&A.flags[o], (uint8_t)flags);
+        if (A.flags) QS_SO(&A.flags[o], (uint8_t)flags);
     }
     store_env(A.st, tile, lane, e);
     if (PARAMS && RMODE == 2) store_par(A.par, tile, lane, P);
