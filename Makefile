@@ -8,7 +8,7 @@ all: lib oracle
 
 lib: $(LIB)
 $(LIB): $(SRC) $(HDR)
-	$(HIPCC) -std=c++20 -O3 -fno-slp-vectorize -ffp-contract=on --offload-arch=gfx950 -fPIC -shared -Wno-unused-result $(SRC) -o $@
+	$(HIPCC) -std=c++20 -O3 -fno-slp-vectorize -ffp-contract=on --offload-arch=gfx950 -fPIC -shared -Wno-unused-result $(SRC) -lhsa-runtime64 -o $@
 
 oracle:
 	$(MAKE) -C oracle

@@ -53,6 +53,10 @@ def parse():
                    help="env groups in flight (qs_set_groups): 1 = one launch per step; G > 1 = G chains on G streams, "
                         "each with a native launcher thread; -1 = the default of this build (see DESIGN.md section 5)")
     p.add_argument("--group-threads", type=int, default=1, help="0: issue the group launches from the calling thread")
+    p.add_argument("--queue-mode", default="auto", choices=["auto", "hip", "private"],
+                   help="private: step launches on an AQL queue owned by the handle, without HIP's end-of-kernel cache write-back "
+                        "(qs_set_queue_mode; bit-identical results); hip: ordinary launches on the HIP stream; auto: private if it "
+                        "opens AND reproduces the HIP-stream chain bit for bit on this machine, else hip")
     p.add_argument("--min-timed-steps", type=int, default=2000,
                    help="the timed interval holds R = ceil(this / K) back-to-back blocks of K steps")
     p.add_argument("--rollout-T", type=int, default=64, help="steps per launch of the fused roll-out leg")
@@ -374,6 +378,27 @@ def main():
             dist.barrier()
         return max_over_ranks(wall), ev_ms
 
+    def verify_private_queue(pool):
+        """The private-queue mode rests on hardware behaviour HIP does not promise (block -> XCD placement).  Before it is
+        used for the headline it has to open on this machine AND reproduce the HIP-stream chain bit for bit: two fresh envs,
+        the same 96 steps (auto-resets included), every output of the last step and the whole final state compared."""
+        a, b = make_env(args.integrator), make_env(args.integrator)
+        try:
+            a.reset(); b.reset()
+            b.set_queue_mode(True)
+            for k in range(96):
+                oa, ra, da, _ = a.step(pool[k % pool.shape[0]])
+                ob, rb, db, _ = b.step(pool[k % pool.shape[0]])
+            torch.cuda.synchronize(); b.sync()
+            same = bool(torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db))
+            sa, sb = a.get_state(as_numpy=False), b.get_state(as_numpy=False)
+            same = same and all(torch.equal(sa[k], sb[k]) for k in sa) and a.step_counter == b.step_counter
+            return same, "ok" if same else "the private-queue chain differs from the HIP-stream chain"
+        except Exception as ex:                                    # noqa: BLE001  (any failure means: do not use the mode)
+            return False, "%s: %s" % (type(ex).__name__, ex)
+        finally:
+            a.close(); b.close()
+
     K, W = args.steps, args.warmup
     R = max(1, -(-args.min_timed_steps // K))
     env = make_env(args.integrator)
@@ -382,6 +407,29 @@ def main():
         groups = env.set_groups(groups, threads=bool(args.group_threads))
     P = max(1, min(args.action_pool, K * R))
     pool = env.random_actions(P, step0=0)               # [P,N,4] U(-1,1), resident in HBM before timing
+    queue_mode, queue_note = "hip", None
+    if args.queue_mode != "hip" and groups <= 1:
+        ok, why = verify_private_queue(pool)
+        if -max_over_ranks(-float(ok)) < 0.5:              # every rank must agree (the legs below hold collective barriers)
+            ok, why = False, why if not ok else "another rank could not verify the private queue"
+        if ok and args.queue_mode == "auto":
+            # ... and it has to be the faster one here (it is not above ~200 000 envs, where the state no longer fits the L2s)
+            probe = max(200, min(1000, K))
+            w_hip, _ = time_steps(env, probe, 1, 50, pool)
+            env.set_queue_mode(True)
+            w_prv, _ = time_steps(env, probe, 1, 50, pool)
+            if w_prv < w_hip:
+                queue_mode = "private"
+            else:
+                env.set_queue_mode(False)
+                queue_note = "private queue verified but slower here (%.2f vs %.2f us per step)" % (w_prv / probe * 1e6, w_hip / probe * 1e6)
+        elif ok:
+            env.set_queue_mode(True)
+            queue_mode = "private"
+        elif args.queue_mode == "private":
+            raise SystemExit("--queue-mode private: " + why)
+        else:
+            queue_note = "private queue not used: " + why
     runs = [time_steps(env, K, R, W, pool, groups) for _ in range(max(1, args.repeats))]
     order = sorted(range(len(runs)), key=lambda i: runs[i][0])
     wall, ev_ms = runs[order[len(order) // 2]]
@@ -409,7 +457,12 @@ def main():
                                "rocRAND randomised auto-reset" % (n, args.env),
                    "envs_per_gpu": n, "total_envs": total_envs, "env": args.env, "integrator": args.integrator,
                    "dt": 0.02, "randomise": args.randomise,
-                   "mode": ("step-API: one qs_step launch per step" if groups <= 1 else
+                   "queue_mode": queue_mode,
+                   "mode": (("step-API: one qs_step launch per step" + (
+                       " on the handle's private AQL queue (packet ordered behind the previous step, acquire at agent scope, no "
+                       "end-of-kernel release: a tile's state stays in the L2 of the XCD that steps it; verified bit-identical to the "
+                       "HIP-stream chain on this machine before timing)" if queue_mode == "private" else " on the HIP stream"))
+                            if groups <= 1 else
                             "step-API: one qs_step_groups call per step = %d launches (env groups of %d envs on %d streams, "
                             "%s), bit-identical to qs_step" % (groups, n // groups, groups,
                                                               "one launcher thread per group" if args.group_threads else "issued by the calling thread")),
@@ -417,7 +470,8 @@ def main():
                    "parallelism": "env-sharded x%d, no data-path collective" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": ("k_env_split<%s> (T=1): two waves per tile" if split else "k_env<%s> (T=1)") % args.integrator,
+                     "kernel": ("k_env_split<%s> (T=1): two waves per tile" if split else "k_env<%s> (T=1)") % args.integrator
+                               + (", dispatched from the handle's private AQL queue" if queue_mode == "private" else ""),
                      "bytes_per_env_step": bpe, "bytes_per_step": bpe * n, "launches_per_step": groups,
                      "step_period_us": step_us,
                      "read_frac": rbpe * n / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
@@ -438,17 +492,33 @@ def main():
                                 "rocprof_kernel_frac": per_launch_bytes / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                 "rocprof_note": "bytes of ONE launch (%d envs) / its average duration in the profiled process "
                                                 "(`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 500 --warmup 50 "
-                                                "--no-extras ...`; the profiler adds a completion signal per dispatch)" % (n // groups)})
+                                                "--no-extras ...`; the profiler wraps every queue and adds a completion signal per "
+                                                "dispatch: the profiled process steps at ~7 us, not %.2f us)" % (n // groups, step_us)})
     # HBM-side bytes per step from the PMC passes (collected separately: rocprofv3 --pmc cannot run inside
     # this process); only quoted when the profile was taken on this very configuration
     try:
         pmc = json.load(open(os.path.join(PROFILE_DIR, "pmc_traffic.json")))
         if pmc["envs"] == n and args.env == "docking-v0" and args.integrator == "frozen" and args.randomise == 1:
-            out["roofline"]["traffic"] = pmc["traffic_bytes_per_step"]
-            out["roofline"]["traffic_source"] = pmc["source"]
+            src = pmc["private_queue"] if queue_mode == "private" and "private_queue" in pmc else pmc
+            out["roofline"]["traffic"] = src["traffic_bytes_per_step"]
+            out["roofline"]["traffic_source"] = pmc["source"] + ("; " + src["note"] if "note" in src else "")
+            if src is not pmc:
+                out["roofline"]["traffic_hip_stream_mode"] = pmc["traffic_bytes_per_step"]
     except (OSError, ValueError, KeyError):
         pass
 
+    if queue_note:
+        out["config"]["queue_note"] = queue_note
+    if queue_mode == "private" and args.no_extras:
+        env.set_queue_mode(False)                          # nothing below steps this env again
+    elif queue_mode == "private":
+        # the same chain as ordinary HIP launches (what round 1 measured), for the difference the release fence makes
+        env.set_queue_mode(False)
+        wh, msh = time_steps(env, K, R, min(W, 50), pool, 1)
+        out["hip_stream_mode"] = {"value": total_envs * steps_timed / wh, "unit": "env-steps/s", "step_period_us": wh * 1e6 / steps_timed,
+                                  "frac": bpe * n / (wh / steps_timed) / 1e9 / HBM_PEAK_GBS,
+                                  "gpu_timeline_us_per_step": msh * 1e3 / steps_timed,
+                                  "what": "identical launches through hipLaunchKernel on the HIP stream (agent-scope release after every kernel)"}
     if not args.no_parity and rank == 0:
         out["parity"] = parity_vs_reference(qa, local_rank)
 

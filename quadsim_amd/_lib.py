@@ -30,6 +30,7 @@ EXPORTS = [
     "qs_step_ex", "qs_set_groups", "qs_group_count", "qs_group_range", "qs_group_stream", "qs_group_set_stream",
     "qs_step_group", "qs_step_groups", "qs_groups_fork", "qs_groups_join",
     "qs_swap_and_flatten_u8", "qs_gae_flatten", "qs_episode_stats", "qs_set_rollout_layout",
+    "qs_set_queue_mode", "qs_get_queue_mode",
 ]
 
 
@@ -76,7 +77,7 @@ def build_library(force=False, verbose=False):
     # -fno-slp-vectorize: SLP packs the scalar f32 chains into v_pk_* pairs at the price of ~300 extra
     # v_mov and +56 VGPRs; measured 5 % slower on the step kernel (profiles/r01/ab_slp.txt)
     cmd = [hipcc_path(), "-std=c++20", "-O3", "-fno-slp-vectorize", "-ffp-contract=on", "--offload-arch=gfx950", "-fPIC", "-shared",
-           "-Wno-unused-result", *SOURCES, "-o", LIB_PATH]
+           "-Wno-unused-result", *SOURCES, "-lhsa-runtime64", "-o", LIB_PATH]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
@@ -152,6 +153,8 @@ def load():
         "qs_gae_flatten": [vp, i64, i64, vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp, vp],
         "qs_episode_stats": [vp, i64, i64, vp, vp, vp, vp, vp, vp, i64, vp, vp, vp],
         "qs_set_rollout_layout": [vp, i32],
+        "qs_set_queue_mode": [vp, i32],
+        "qs_get_queue_mode": [vp, C.POINTER(i32)],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

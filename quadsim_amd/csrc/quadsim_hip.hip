@@ -12,6 +12,14 @@
 // See include/quadsim.h for the contract of each entry point and the reference
 // file:line it replaces.
 #include <hip/hip_runtime.h>
+#include <hsa/hsa.h>
+#include <hsa/hsa_ext_amd.h>
+
+#include <elf.h>
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -111,6 +119,10 @@ struct StepArgs {
     int randomise;
     float nominal_obs[12]; // state2rel of the nominal reset states (what a non-randomised reset returns)
     const float *init;     // stored per-env initial states: [N][26] (docking: chaser, target) / [N][13] (hovering)
+    // private-queue launches (qs_set_queue_mode): the launch carries no release fence, so a tile's state stays dirty in the L2 of
+    // the XCD that stepped it; `owner` [tiles] records that XCD and every workgroup checks that it runs where its tile lives
+    unsigned char *owner;  // nullptr: ordinary (fenced) launch, no check
+    unsigned *err;         // device word: bit 0 set when a workgroup found its tile owned by another XCD (it then touches nothing)
 };
 
 __device__ __forceinline__ void load_env(const float *__restrict__ st, int64_t tile, int lane, Env &e)
@@ -191,6 +203,34 @@ __device__ __forceinline__ void step_counter_end(const StepArgs &A, int64_t tile
     if (lane == 0) A.ctr[tile] = k + (uint64_t)A.T;
 }
 
+// private-queue launches only: true when this wave must not touch its tile (the tile's latest state is in another XCD's L2).
+// Blocks are dealt to the XCDs round-robin from a start that is constant for a queue (measured: tools/xcc_map.hip), so this
+// never fires; it turns a change of that hardware behaviour into a loud error instead of stale state.
+// the same check for a caller that requested A.owner[tile] earlier (no load latency on its critical path)
+__device__ __forceinline__ bool chain_owner_mismatch(const StepArgs &A, int64_t tile, int lane, unsigned own)
+{
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;   // HW_REG_XCC_ID
+    if (own != 0xffu && own != xcc) {
+        if (lane == 0) atomicOr(A.err, 1u);
+        return true;
+    }
+    if (lane == 0 && own == 0xffu) A.owner[tile] = (unsigned char)xcc;
+    return false;
+}
+
+__device__ __forceinline__ bool chain_tile_misplaced(const StepArgs &A, int64_t tile, int lane)
+{
+    if (!A.owner) return false;
+    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;   // HW_REG_XCC_ID
+    const unsigned own = A.owner[tile];
+    if (own != 0xffu && own != xcc) {
+        if (lane == 0) atomicOr(A.err, 1u);
+        return true;
+    }
+    if (lane == 0 && own == 0xffu) A.owner[tile] = (unsigned char)xcc;
+    return false;
+}
+
 // RMODE (compile time) = the handle's `randomise`: 0 nominal reset, 1 rocRAND init state, 2 + params.
 template <int INTEG, bool PARAMS, int RMODE>
 __device__ __forceinline__ void step_and_maybe_reset(Env &e, Par &P, const float a[4], const StepArgs &A, int64_t env,
@@ -243,6 +283,7 @@ __global__ __launch_bounds__(kBlock) void k_env(StepArgs A)
     const int64_t tile = A.tile0 + (int64_t)blockIdx.x * (kBlock / kTile) + (threadIdx.x >> 6);
     const int64_t env = tile * kTile + lane;
     if (tile >= A.tile_end || env >= A.n) return;
+    if (chain_tile_misplaced(A, tile, lane)) return;
     const int64_t io = env - A.io_env0;          // row of this env in the I/O arrays
     QS_ASSERT(io >= 0 && io < A.io_n);
     const uint64_t k0 = step_counter_begin(A, tile);
@@ -305,9 +346,12 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
     const int role = threadIdx.x >> 6;
     const int64_t tile = A.tile0 + blockIdx.x;   // grid = the tiles of this launch's env group
     const int64_t env = tile * kTile + lane;
-    const bool active = env < A.n;               // idle lanes of the tail tile compute on zeros and store nothing
+    bool active = env < A.n;                     // idle lanes of the tail tile compute on zeros and store nothing
     const int64_t io = env - A.io_env0;          // row of this env in the I/O arrays
     QS_ASSERT(tile < A.tile_end && (!active || (io >= 0 && io < A.io_n)));
+    // private-queue launches: the tile's owning XCD is requested here and examined only after the first compute phase (below),
+    // so that the check costs no memory latency; a misplaced workgroup computes on whatever it loaded and stores nothing
+    const unsigned owner_xcc = A.owner ? A.owner[tile] : 0xffu;
     const uint64_t k0 = step_counter_begin(A, tile);
     QS_STAMP_DECL;
     QS_STAMP_AT(0);
@@ -340,6 +384,7 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
             const int64_t o = t * A.io_n + io;
             tt += 1.0f;
             const bool lim_c = drone_advance<INTEG>(sc, uc, P, A.C.dt);   // Drone.step's integration: previous control only
+            if (A.owner && chain_owner_mismatch(A, tile, lane, owner_xcc)) active = false;
             float a[4];
             if (A.actions) {
                 const float4 av = av_next;
@@ -424,7 +469,7 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
             QS_ST(&bw[F_T * kTile], tt);
             if (PARAMS && RMODE == 2) store_par(A.par, tile, lane, P);
         }
-        step_counter_end(A, tile, lane, k0);
+        if (!A.owner || active || env >= A.n) step_counter_end(A, tile, lane, k0);   // a misplaced tile's counter stays put, too
 #ifdef QS_STAMP
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
@@ -453,6 +498,7 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
 #pragma unroll
             for (int i = 0; i < 13; ++i) pre[i] = st[i];
             const bool lim_t = drone_advance<INTEG>(st, ut, P, A.C.dt);   // with the previous limited control
+            if (A.owner && chain_owner_mismatch(A, tile, lane, owner_xcc)) active = false;
 #pragma unroll
             for (int i = 0; i < 13; ++i) s_tgt[i][lane] = st[i];
             s_limt[lane] = lim_t ? 1 : 0;
@@ -1169,6 +1215,7 @@ struct QsEnv {
     bool main_dirty = true;     // the handle enqueued work on its main stream that the group streams have not been ordered behind
     bool groups_dirty = false;  // group streams hold work the main stream has not been ordered behind
     bool runner_env_major = false;   // qs_set_rollout_layout
+    struct QsChain *chain = nullptr; // qs_set_queue_mode: private AQL queue for the step launches
 };
 
 namespace {
@@ -1449,11 +1496,340 @@ void groups_destroy(QsEnv *e)
     e->main_dirty = true;
 }
 
-// entry points that use the main stream: order it behind pending group work first, and mark it dirty for the groups
+}  // namespace
+
+// ---- private AQL queue for the step launches (qs_set_queue_mode) -------------------------------------------------------
+// Every kernel HIP launches ends with an agent-scope release: the eight XCD L2s are not coherent with each other, so their
+// dirty lines are written back before the next packet may start.  For a chain of dependent step launches that write-back is
+// 1.6 of 6.5 us per step at 65 536 envs (profiles/r02/ab_experiments.txt, section E) -- and it is not needed: tile b is
+// stepped by workgroup b of every launch, workgroup b always lands on the same XCD, so the tile's state can stay dirty in
+// that XCD's L2 from one step to the next.  HIP has no launch without the fence; an AQL packet written by hand has:
+//     header = KERNEL_DISPATCH | BARRIER (ordered behind the previous packet) | ACQUIRE agent (fresh kernargs / actions;
+//              0.16 us, does not touch dirty lines) | RELEASE none.
+// The handle therefore owns an HSA queue, loads its own copy of the library's code object into it, and writes one packet per
+// qs_step.  Everything else stays on HIP: any other entry point first DRAINS the queue with a release packet (host wait), and
+// the first step after HIP-side work waits for the handle's stream.  What the caller has in flight on HIP streams is not
+// ordered against the queue: inputs must be complete when qs_step is called, outputs are valid after qs_sync (pre-staged
+// actions, roll-outs; with a policy between the steps use the default mode).
+struct QsChain {
+    hsa_agent_t gpu{}, cpu{};
+    hsa_amd_memory_pool_t kernarg_pool{};
+    hsa_queue_t *queue = nullptr;
+    hsa_executable_t exe{};
+    hsa_code_object_reader_t reader{};
+    bool have_exe = false, have_reader = false;
+    std::vector<char> image;          // the gfx950 code object (kept alive for the executable)
+    uint64_t kernel_object = 0;
+    uint32_t kernarg_size = 0, group_size = 0, private_size = 0;
+    unsigned block = 0;
+    char *kernargs = nullptr;
+    size_t stride = 0, slots = 0;
+    uint64_t issued = 0;              // step packets written so far
+    std::vector<uint64_t> slot_qidx;  // queue index of the packet that last used each kernarg slot
+    hsa_signal_t done{};
+    unsigned char *d_owner = nullptr; // [tiles]
+    unsigned *d_err = nullptr;
+    bool kernargs_on_device = false;  // kernarg ring in BAR-mapped device memory (else: host memory, correct but slow)
+    bool dirty = false;               // packets enqueued since the last drain
+    bool hip_dirty = true;            // the handle did HIP-side work since the last packet
+};
+
+namespace {
+
+#define HSA_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hsa_status_t s_ = (expr);                                                                       \
+        if (s_ != HSA_STATUS_SUCCESS) {                                                                 \
+            const char *m_ = nullptr;                                                                   \
+            hsa_status_string(s_, &m_);                                                                 \
+            return fail(QS_ERR_HIP, "%s failed: %s", #expr, m_ ? m_ : "unknown HSA status");           \
+        }                                                                                               \
+    } while (0)
+
+struct AgentPick {
+    uint32_t want_bdf;
+    int want_index, seen;
+    hsa_agent_t gpu, cpu;
+    bool have_gpu, have_cpu;
+};
+
+hsa_status_t chain_agent_cb(hsa_agent_t a, void *data)
+{
+    AgentPick *p = (AgentPick *)data;
+    hsa_device_type_t t;
+    if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
+    if (t == HSA_DEVICE_TYPE_CPU && !p->have_cpu) { p->cpu = a; p->have_cpu = true; }
+    if (t == HSA_DEVICE_TYPE_GPU) {
+        uint32_t bdf = 0;
+        const bool ok = hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf) == HSA_STATUS_SUCCESS;
+        // BDFID = bus << 8 | device << 3 | function
+        if ((ok && p->want_bdf != 0xffffffffu) ? bdf == p->want_bdf : p->seen == p->want_index) { p->gpu = a; p->have_gpu = true; }
+        ++p->seen;
+    }
+    return HSA_STATUS_SUCCESS;
+}
+
+// device-local memory the host may write through the PCIe BAR: where HIP itself keeps kernel arguments on this platform
+// (kernargs in host memory would cost every workgroup a PCIe read: 44 us per step instead of 5)
+struct DevPoolPick {
+    hsa_agent_t cpu;
+    hsa_amd_memory_pool_t pool;
+    bool found;
+};
+hsa_status_t chain_device_pool_cb(hsa_amd_memory_pool_t pool, void *data)
+{
+    DevPoolPick *p = (DevPoolPick *)data;
+    hsa_amd_segment_t seg;
+    if (hsa_amd_memory_pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_SEGMENT, &seg) != HSA_STATUS_SUCCESS || seg != HSA_AMD_SEGMENT_GLOBAL)
+        return HSA_STATUS_SUCCESS;
+    uint32_t flags = 0;
+    bool alloc = false;
+    hsa_amd_memory_pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_GLOBAL_FLAGS, &flags);
+    hsa_amd_memory_pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_RUNTIME_ALLOC_ALLOWED, &alloc);
+    if (!alloc || !(flags & HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_COARSE_GRAINED)) return HSA_STATUS_SUCCESS;
+    hsa_amd_memory_pool_access_t acc = HSA_AMD_MEMORY_POOL_ACCESS_NEVER_ALLOWED;
+    hsa_amd_agent_memory_pool_get_info(p->cpu, pool, HSA_AMD_AGENT_MEMORY_POOL_INFO_ACCESS, &acc);
+    if (acc == HSA_AMD_MEMORY_POOL_ACCESS_NEVER_ALLOWED) return HSA_STATUS_SUCCESS;
+    p->pool = pool;
+    p->found = true;
+    return HSA_STATUS_INFO_BREAK;
+}
+
+hsa_status_t chain_kernarg_pool_cb(hsa_amd_memory_pool_t pool, void *data)
+{
+    hsa_amd_segment_t seg;
+    if (hsa_amd_memory_pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_SEGMENT, &seg) != HSA_STATUS_SUCCESS || seg != HSA_AMD_SEGMENT_GLOBAL)
+        return HSA_STATUS_SUCCESS;
+    uint32_t flags = 0;
+    hsa_amd_memory_pool_get_info(pool, HSA_AMD_MEMORY_POOL_INFO_GLOBAL_FLAGS, &flags);
+    if (flags & HSA_AMD_MEMORY_POOL_GLOBAL_FLAG_KERNARG_INIT) { *(hsa_amd_memory_pool_t *)data = pool; return HSA_STATUS_INFO_BREAK; }
+    return HSA_STATUS_SUCCESS;
+}
+
+// the gfx950 code object of THIS library: the .hip_fatbin section of the shared object the code runs from holds a clang
+// offload bundle; its amdgcn entry is the ELF that HIP itself loads
+int chain_read_code_object(std::vector<char> &out)
+{
+    Dl_info di;
+    if (!dladdr((void *)&chain_read_code_object, &di) || !di.dli_fname) return fail(QS_ERR_HIP, "queue mode: cannot locate the library file");
+    const int fd = open(di.dli_fname, O_RDONLY);
+    if (fd < 0) return fail(QS_ERR_HIP, "queue mode: cannot open %s", di.dli_fname);
+    struct stat st;
+    if (fstat(fd, &st) != 0) { close(fd); return fail(QS_ERR_HIP, "queue mode: fstat failed"); }
+    const char *base = (const char *)mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
+    close(fd);
+    if (base == MAP_FAILED) return fail(QS_ERR_HIP, "queue mode: mmap failed");
+    int rc = fail(QS_ERR_HIP, "queue mode: no gfx950 code object in %s", di.dli_fname);
+    const Elf64_Ehdr *eh = (const Elf64_Ehdr *)base;
+    const Elf64_Shdr *sh = (const Elf64_Shdr *)(base + eh->e_shoff);
+    const char *names = base + sh[eh->e_shstrndx].sh_offset;
+    for (int i = 0; i < eh->e_shnum; ++i) {
+        if (strcmp(names + sh[i].sh_name, ".hip_fatbin") != 0) continue;
+        const char *fb = base + sh[i].sh_offset;
+        const char magic[] = "__CLANG_OFFLOAD_BUNDLE__";
+        if (sh[i].sh_size < 32 || memcmp(fb, magic, 24) != 0) break;
+        uint64_t n;
+        memcpy(&n, fb + 24, 8);
+        const char *q = fb + 32;
+        for (uint64_t k = 0; k < n; ++k) {
+            uint64_t off, size, tl;
+            memcpy(&off, q, 8); memcpy(&size, q + 8, 8); memcpy(&tl, q + 16, 8);
+            const char *triple = q + 24;
+            q += 24 + tl;
+            if (tl >= 6 && memmem(triple, tl, "amdgcn", 6) && memmem(triple, tl, "gfx950", 6) && off + size <= sh[i].sh_size) {
+                out.assign(fb + off, fb + off + size);
+                rc = QS_OK;
+            }
+        }
+        break;
+    }
+    munmap((void *)base, (size_t)st.st_size);
+    return rc;
+}
+
+void chain_close(QsEnv *e)
+{
+    QsChain *c = e->chain;
+    if (!c) return;
+    if (c->queue) hsa_queue_destroy(c->queue);
+    if (c->kernargs) hsa_amd_memory_pool_free(c->kernargs);
+    if (c->done.handle) hsa_signal_destroy(c->done);
+    if (c->have_exe) hsa_executable_destroy(c->exe);
+    if (c->have_reader) hsa_code_object_reader_destroy(c->reader);
+    if (c->d_owner) (void)hipFree(c->d_owner);
+    if (c->d_err) (void)hipFree(c->d_err);
+    delete c;
+    e->chain = nullptr;
+}
+
+int chain_open(QsEnv *e)
+{
+    if (e->cfg.kind == QS_KIND_HOVERING_V0) return fail(QS_ERR_INVALID, "qs_set_queue_mode: docking envs only");
+    if (e->cfg.io_space != QS_IO_DEVICE) return fail(QS_ERR_INVALID, "qs_set_queue_mode: device buffers only");
+    QsChain *c = new (std::nothrow) QsChain();
+    if (!c) return fail(QS_ERR_NOMEM, "qs_set_queue_mode: out of host memory");
+    e->chain = c;
+    auto body = [&]() -> int {
+        HSA_TRY(hsa_init());
+        char bus[32] = "";
+        AgentPick pick{0xffffffffu, e->cfg.device, 0, {}, {}, false, false};
+        unsigned dom = 0, b = 0, d = 0, f = 0;
+        if (hipDeviceGetPCIBusId(bus, sizeof bus, e->cfg.device) == hipSuccess && sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &f) == 4)
+            pick.want_bdf = (b << 8) | (d << 3) | f;
+        HSA_TRY(hsa_iterate_agents(chain_agent_cb, &pick));
+        if (!pick.have_gpu || !pick.have_cpu) return fail(QS_ERR_HIP, "qs_set_queue_mode: no HSA agent for device %d (%s)", e->cfg.device, bus);
+        c->gpu = pick.gpu; c->cpu = pick.cpu;
+        hsa_status_t ps = hsa_amd_agent_iterate_memory_pools(c->cpu, chain_kernarg_pool_cb, &c->kernarg_pool);
+        if (ps != HSA_STATUS_INFO_BREAK) return fail(QS_ERR_HIP, "qs_set_queue_mode: no kernarg memory pool");
+        int r = chain_read_code_object(c->image);
+        if (r) return r;
+        HSA_TRY(hsa_code_object_reader_create_from_memory(c->image.data(), c->image.size(), &c->reader));
+        c->have_reader = true;
+        HSA_TRY(hsa_executable_create_alt(HSA_PROFILE_FULL, HSA_DEFAULT_FLOAT_ROUNDING_MODE_DEFAULT, nullptr, &c->exe));
+        c->have_exe = true;
+        HSA_TRY(hsa_executable_load_agent_code_object(c->exe, c->gpu, c->reader, nullptr, nullptr));
+        HSA_TRY(hsa_executable_freeze(c->exe, nullptr));
+        // the instantiation launch_env_on would pick for this handle
+        const int integ = e->cfg.integrator == QS_INTEG_FROZEN ? 0 : 1;
+        const int rmode = e->init ? 3 : e->cfg.randomise;
+        const int params = (rmode == 2 || e->per_env_params) ? 1 : 0;
+        static const int forced = getenv("QS_SPLIT") ? atoi(getenv("QS_SPLIT")) : -1;
+        const bool split = forced >= 0 ? forced != 0 : e->n <= kSplitMaxEnvs;
+        char sym[160];
+        snprintf(sym, sizeof sym, split ? "_ZN12_GLOBAL__N_111k_env_splitILi%dELb%dELi%dEEEvNS_8StepArgsE.kd"
+                                        : "_ZN12_GLOBAL__N_15k_envILi%dELb%dELi%dEEEvNS_8StepArgsE.kd", integ, params, rmode);
+        c->block = split ? 2 * kTile : kBlock;
+        hsa_executable_symbol_t ks;
+        HSA_TRY(hsa_executable_get_symbol_by_name(c->exe, sym, &c->gpu, &ks));
+        HSA_TRY(hsa_executable_symbol_get_info(ks, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &c->kernel_object));
+        HSA_TRY(hsa_executable_symbol_get_info(ks, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &c->kernarg_size));
+        HSA_TRY(hsa_executable_symbol_get_info(ks, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &c->group_size));
+        HSA_TRY(hsa_executable_symbol_get_info(ks, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &c->private_size));
+        if (c->kernarg_size < sizeof(StepArgs)) return fail(QS_ERR_HIP, "qs_set_queue_mode: kernel argument block is %u B, StepArgs %zu B", c->kernarg_size, sizeof(StepArgs));
+        HSA_TRY(hsa_queue_create(c->gpu, 4096, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &c->queue));
+        c->stride = ((size_t)c->kernarg_size + 255) & ~size_t(255);
+        // a small ring: a slot is rewritten only after its packet ran, and recently used kernarg lines are still in the caches
+        // (4 096 slots: 5.43 us per step, 256: 5.27, 64 and 16: 5.24, 4: host-bound; profiles/r02/ab_experiments.txt, section E)
+        c->slots = getenv("QS_CHAIN_SLOTS") ? (size_t)atoi(getenv("QS_CHAIN_SLOTS")) : 64;
+        if (c->slots < 2 || c->slots > 4096) c->slots = 64;
+        c->slot_qidx.assign(c->slots, 0);
+        DevPoolPick dp{c->cpu, {}, false};
+        (void)hsa_amd_agent_iterate_memory_pools(c->gpu, chain_device_pool_cb, &dp);
+        if (dp.found) {
+            HSA_TRY(hsa_amd_memory_pool_allocate(dp.pool, c->stride * c->slots, 0, (void **)&c->kernargs));
+            HSA_TRY(hsa_amd_agents_allow_access(1, &c->cpu, nullptr, c->kernargs));
+            c->kernargs_on_device = true;
+        } else {
+            HSA_TRY(hsa_amd_memory_pool_allocate(c->kernarg_pool, c->stride * c->slots, 0, (void **)&c->kernargs));
+            HSA_TRY(hsa_amd_agents_allow_access(1, &c->gpu, nullptr, c->kernargs));
+        }
+        memset(c->kernargs, 0, c->stride * c->slots);      // the hidden arguments behind StepArgs are never read: zeros
+        HSA_TRY(hsa_signal_create(0, 0, nullptr, &c->done));
+        HIP_TRY(hipMalloc((void **)&c->d_owner, (size_t)e->tiles));
+        HIP_TRY(hipMalloc((void **)&c->d_err, sizeof(unsigned)));
+        HIP_TRY(hipMemset(c->d_err, 0, sizeof(unsigned)));
+        return QS_OK;
+    };
+    const int rc = body();
+    if (rc != QS_OK) chain_close(e);
+    return rc;
+}
+
+// one AQL packet: the step kernel (or, kernel_object == 0, a barrier packet) behind everything enqueued before it
+uint64_t chain_write_packet(QsChain *c, bool barrier_only, const void *kernarg, unsigned grid, int acquire, int release, bool signal)
+{
+    const uint64_t idx = hsa_queue_add_write_index_relaxed(c->queue, 1);
+    while (idx - hsa_queue_load_read_index_scacquire(c->queue) >= c->queue->size) __builtin_ia32_pause();
+    void *slot = (char *)c->queue->base_address + (idx & (c->queue->size - 1)) * 64;
+    uint16_t header;
+    if (barrier_only) {
+        hsa_barrier_and_packet_t *p = (hsa_barrier_and_packet_t *)slot;
+        memset((char *)p + 2, 0, 62);
+        p->completion_signal = signal ? c->done : hsa_signal_t{0};
+        header = (HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE);
+    } else {
+        hsa_kernel_dispatch_packet_t *p = (hsa_kernel_dispatch_packet_t *)slot;
+        p->setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
+        p->workgroup_size_x = (uint16_t)c->block; p->workgroup_size_y = 1; p->workgroup_size_z = 1;
+        p->reserved0 = 0;
+        p->grid_size_x = grid; p->grid_size_y = 1; p->grid_size_z = 1;
+        p->private_segment_size = c->private_size;
+        p->group_segment_size = c->group_size;
+        p->kernel_object = c->kernel_object;
+        p->kernarg_address = (void *)kernarg;
+        p->reserved2 = 0;
+        p->completion_signal = signal ? c->done : hsa_signal_t{0};
+        header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE);
+    }
+    header |= (1 << HSA_PACKET_HEADER_BARRIER) | (acquire << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
+              (release << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+    __atomic_store_n((uint16_t *)slot, header, __ATOMIC_RELEASE);
+    hsa_signal_store_screlease(c->queue->doorbell_signal, (hsa_signal_value_t)idx);
+    return idx;
+}
+
+// every packet has run and what it wrote is visible to the whole system (host wait); reports a misplaced tile
+int chain_drain(QsEnv *e)
+{
+    QsChain *c = e->chain;
+    if (!c || !c->dirty) return QS_OK;
+    hsa_signal_store_relaxed(c->done, 1);
+    chain_write_packet(c, true, nullptr, 0, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_SYSTEM, true);
+    while (hsa_signal_wait_scacquire(c->done, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_ACTIVE) != 0) {}
+    c->dirty = false;
+    unsigned err = 0;
+    HIP_TRY(hipMemcpy(&err, c->d_err, sizeof err, hipMemcpyDeviceToHost));
+    if (err) {
+        (void)hipMemset(c->d_err, 0, sizeof err);
+        return fail(QS_ERR_HIP, "queue mode: a workgroup ran on another XCD than the one holding its tile; the steps since the last "
+                                "synchronisation are invalid (this placement is not promised by HIP: use qs_set_queue_mode(env, 0))");
+    }
+    return QS_OK;
+}
+
+int chain_step(QsEnv *e, const StepArgs &A0)
+{
+    QsChain *c = e->chain;
+    if (c->hip_dirty) {
+        // HIP-side work of the handle (reset, set_state, ...) must have finished, and no tile has an owning XCD yet
+        HIP_TRY(hipMemsetAsync(c->d_owner, 0xff, (size_t)e->tiles, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        c->hip_dirty = false;
+    }
+    StepArgs A = A0;
+    A.owner = c->d_owner;
+    A.err = c->d_err;
+    // the slot about to be rewritten belongs to step `issued - slots`, queue packet q: that kernel has FINISHED once the packet
+    // behind it has been taken off the queue (every packet carries the barrier bit), i.e. once the read index has passed q + 1
+    const size_t sl = c->issued % c->slots;
+    if (c->issued >= c->slots)
+        while (hsa_queue_load_read_index_scacquire(c->queue) < c->slot_qidx[sl] + 2) __builtin_ia32_pause();
+    char *ka = c->kernargs + sl * c->stride;
+    memcpy(ka, &A, sizeof A);
+    if (c->kernargs_on_device) {
+        // posted writes through the BAR: read the last word back so that they have landed before the doorbell rings
+        __builtin_ia32_sfence();
+        (void)*(volatile uint32_t *)(ka + sizeof A - sizeof(uint32_t));
+    }
+    const int64_t tiles = A.tile_end - A.tile0;
+    const unsigned grid = c->block == 2 * kTile ? (unsigned)(tiles * c->block)
+                                                : (unsigned)(((tiles + kBlock / kTile - 1) / (kBlock / kTile)) * kBlock);
+    c->slot_qidx[sl] = chain_write_packet(c, false, ka, grid, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_NONE, false);
+    ++c->issued;
+    c->dirty = true;
+    return QS_OK;
+}
+
+// entry points that use the main stream: order it behind pending group work / the private queue first
 int main_stream_entry(QsEnv *e)
 {
     if (e->groups_dirty) { int rc = groups_join(e); if (rc) return rc; }
     e->main_dirty = true;
+    if (e->chain) {
+        int rc = chain_drain(e);
+        e->chain->hip_dirty = true;
+        if (rc) return rc;
+    }
     return QS_OK;
 }
 
@@ -1484,7 +1860,7 @@ int do_reset(QsEnv *e, const uint8_t *d_mask, float *d_obs, int init_all)
     if (!guard_.ok) return fail(QS_ERR_HIP, "%s: hipSetDevice(%d) failed", __func__, (e)->cfg.device)
 #define CHECK_ENV(e)                                                   \
     CHECK_ENV_RAW(e);                                                  \
-    if (!(e)->groups.empty()) { int rcj_ = main_stream_entry(e); if (rcj_) return rcj_; }
+    if (!(e)->groups.empty() || (e)->chain) { int rcj_ = main_stream_entry(e); if (rcj_) return rcj_; }
 
 }  // namespace
 
@@ -1503,6 +1879,24 @@ int qs_debug_set_stamps(void *dev_ptr, uint64_t capacity_words)
 }
 #endif
 const char *qs_last_error(void) { return g_err; }
+
+// Diagnostic (not in quadsim.h; used by tools/hsa_chain_exp.py only): the kernel-argument block qs_step would pass to the
+// step kernel for these buffers, so that an experiment can dispatch the very same kernel through a queue of its own.
+int qs_debug_step_kernargs(QsEnv *e, const float *actions, float *obs, float *reward, uint8_t *done, uint8_t *flags,
+                           float *terminal_obs, void *out, uint64_t cap, uint64_t *size, int32_t *split, int64_t *tiles,
+                           int64_t tile0, int64_t tile_end)
+{
+    if (!e || !out || !size) return fail(QS_ERR_INVALID, "qs_debug_step_kernargs: null argument");
+    StepArgs A = make_args(e);
+    if (tile_end > tile0) { A.tile0 = tile0; A.tile_end = tile_end; }
+    A.actions = actions; A.obs = obs; A.reward = reward; A.done = done; A.flags = flags; A.term_obs = terminal_obs;
+    if (cap < sizeof A) return fail(QS_ERR_INVALID, "qs_debug_step_kernargs: buffer too small (%zu needed)", sizeof A);
+    memcpy(out, &A, sizeof A);
+    *size = sizeof A;
+    if (split) *split = e->n <= kSplitMaxEnvs ? 1 : 0;
+    if (tiles) *tiles = e->tiles;
+    return QS_OK;
+}
 
 int qs_config_default(QsConfig *cfg)
 {
@@ -1612,6 +2006,7 @@ int qs_destroy(QsEnv *e)
     if (!e) return QS_OK;
     DeviceGuard guard(e->cfg.device);
     groups_destroy(e);
+    if (e->chain) { (void)chain_drain(e); chain_close(e); }
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     if (e->st) (void)hipFree(e->st);
     if (e->par) (void)hipFree(e->par);
@@ -1714,10 +2109,19 @@ int qs_step_ex(QsEnv *e, const float *actions, float *obs, float *reward, uint8_
                float *terminal_state)
 {
     Range rg_("qs_step_ex");
-    CHECK_ENV(e);
+    CHECK_ENV_RAW(e);
     if (!actions || !obs || !reward || !done) return fail(QS_ERR_INVALID, "qs_step: actions, obs, reward and done are required");
     if (terminal_state && e->cfg.kind == QS_KIND_HOVERING_V0)
         return fail(QS_ERR_INVALID, "qs_step_ex: hovering-v0 has no terminal_state (its terminal observation IS the state)");
+    if (e->chain) {
+        // private-queue mode: one hand-written AQL packet behind the previous step's; nothing of the HIP stream is touched
+        if (e->groups_dirty) { int rj = groups_join(e); if (rj) return rj; HIP_TRY(hipStreamSynchronize(e->stream)); }
+        StepArgs A = make_args(e);
+        A.actions = actions; A.obs = obs; A.reward = reward; A.done = done; A.flags = flags; A.term_obs = terminal_obs;
+        A.term_state = terminal_state;
+        return chain_step(e, A);
+    }
+    if (!e->groups.empty()) { int rcj = main_stream_entry(e); if (rcj) return rcj; }
     const int64_t n = e->n;
     StepArgs A = make_args(e);
     int r;
@@ -1964,7 +2368,7 @@ int qs_rollout_stepwise(QsEnv *e, int64_t T, const float *actions, float *obs, f
         A.reward = reward + t * n;
         A.done = done + t * n;
         A.flags = flags ? flags + t * n : nullptr;
-        int r = launch_env(e, A);
+        int r = e->chain ? chain_step(e, A) : launch_env(e, A);    // queue mode: T packets, drained by the next entry point
         if (r) return r;
     }
     return QS_OK;
@@ -2371,6 +2775,36 @@ int qs_runner_rollout_fast(QsEnv *e, int64_t T, const void *packed_weights, cons
 }
 
 int qs_runner_rollout_fast_blob_bytes(void) { return kAcFastBlobBytes; }
+
+int qs_set_queue_mode(QsEnv *e, int32_t mode)
+{
+    CHECK_ENV(e);                                     // drains a queue that is being switched off
+    if (mode != QS_QUEUE_HIP_STREAM && mode != QS_QUEUE_PRIVATE) return fail(QS_ERR_INVALID, "qs_set_queue_mode: unknown mode %d", mode);
+    if (mode == QS_QUEUE_HIP_STREAM) { chain_close(e); return QS_OK; }
+    if (e->chain) return QS_OK;
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return chain_open(e);
+}
+
+// Diagnostic (not in quadsim.h; tests only): pretend every tile is held by an XCD that does not exist, so that the placement
+// check of the next private-queue step fires in every workgroup
+int qs_debug_chain_poison_owner(QsEnv *e)
+{
+    if (!e || !e->chain) return fail(QS_ERR_INVALID, "qs_debug_chain_poison_owner: not in private-queue mode");
+    DeviceGuard guard(e->cfg.device);
+    int rc = chain_drain(e);
+    if (rc) return rc;
+    HIP_TRY(hipMemset(e->chain->d_owner, 9, (size_t)e->tiles));
+    e->chain->hip_dirty = false;          // keep the poisoned owners: the next step must not reset them
+    return QS_OK;
+}
+
+int qs_get_queue_mode(QsEnv *e, int32_t *mode)
+{
+    if (!e || !mode) return fail(QS_ERR_INVALID, "qs_get_queue_mode: null argument");
+    *mode = e->chain ? QS_QUEUE_PRIVATE : QS_QUEUE_HIP_STREAM;
+    return QS_OK;
+}
 
 int qs_set_rollout_layout(QsEnv *e, int32_t layout)
 {

@@ -342,3 +342,98 @@ def test_c_abi_argument_checks_of_the_new_entry_points(qa):
     assert lib.qs_episode_stats(h, 1, 1, *([None] * 6), 0, None, None, None) != 0
     assert lib.qs_set_groups(h, 1, 0) == 0
     env.close()
+
+
+# ---------------------------------------------------------------- private-queue mode (qs_set_queue_mode)
+@pytest.mark.parametrize("n,env_id,rnd,integ", [(65536, "docking-v0", 1, "frozen"), (1000, "docking-v2", 2, "frozen"),
+                                                (4096, "docking-v0", 0, "rk4"), (262144, "docking-v0", 1, "frozen")])
+def test_private_queue_chain_bit_identical_to_hip_stream(qa, torch, n, env_id, rnd, integ):
+    """step launches as hand-written AQL packets without the end-of-kernel release (the tile's state stays in its XCD's L2)
+    == ordinary HIP launches, bit for bit: every step's outputs, terminal rows, the final state, the step counter; with
+    main-stream calls (masked reset, set_state) in between, through both step kernels (split / serial), ragged tiles"""
+    kw = dict(num_envs=n, randomise=rnd, seed=21, init_range=qa.C3_INIT_RANGE, mass_scale=(0.8, 1.2), inertia_scale=(0.8, 1.2),
+              integrator=integ, copy=False)
+    a, b = qa.VecDockingEnv(env_id, **kw), qa.VecDockingEnv(env_id, **kw)
+    b.set_queue_mode(True)
+    assert b.queue_mode == "private" and a.queue_mode == "hip-stream"
+    a.reset(); b.reset()
+    t0 = np.zeros(n, np.float32); t0[::7] = 590.0
+    a.set_state(t=t0); b.set_state(t=t0)
+    acts = a.random_actions(40, step0=0)
+    n_done = 0
+    for k in range(40):
+        oa, ra, da, _ = a.step(acts[k])
+        ob, rb, db, _ = b.step(acts[k])                    # step_wait drains the queue in this mode
+        torch.cuda.synchronize()
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db) and torch.equal(a._flags, b._flags), k
+        if bool(da.any()):
+            assert torch.equal(a._term[da], b._term[db]) and torch.equal(a._tstate[da], b._tstate[db])
+        n_done += int(da.sum())
+        if k == 17:
+            mask = np.zeros(n, np.uint8); mask[::3] = 1
+            ra_, rb_ = a.reset(mask), b.reset(mask)         # a HIP-stream call in the middle of the chain
+            assert torch.equal(ra_, rb_)
+    assert n_done > n // 10
+    np.testing.assert_array_equal(_full_state(a), _full_state(b))
+    assert a.step_counter == b.step_counter == 40
+    # T steps enqueued back to back with ONE drain at the end (qs_rollout_stepwise): the way the mode is meant to be used
+    o1, r1, d1, f1 = a.rollout(acts[:16], stepwise=True)
+    o2, r2, d2, f2 = b.rollout(acts[:16], stepwise=True)
+    torch.cuda.synchronize()
+    assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2) and torch.equal(f1, f2)
+    np.testing.assert_array_equal(_full_state(a), _full_state(b))
+    b.set_queue_mode(False)                                 # and back: the chain continues on the HIP stream
+    oa, _, _, _ = a.step(acts[0]); ob, _, _, _ = b.step(acts[0])
+    torch.cuda.synchronize()
+    assert torch.equal(oa, ob)
+    a.close(); b.close()
+
+
+def test_private_queue_many_steps_and_raw_loop(qa, torch):
+    """the bench's use: thousands of qs_step packets with no synchronisation in between (the kernarg ring wraps), then one sync"""
+    import ctypes as C
+    n, K = 65536, 6000
+    kw = dict(num_envs=n, randomise=1, seed=5, init_range=qa.C3_INIT_RANGE, copy=False)
+    a, b = qa.VecDockingEnv("docking-v0", **kw), qa.VecDockingEnv("docking-v0", **kw)
+    a.reset(); b.reset()
+    b.set_queue_mode(True)
+    pool = a.random_actions(64, step0=0)
+    p = lambda t: C.c_void_p(t.data_ptr())                 # noqa: E731
+    for env in (a, b):
+        lib, h = env._lib, env._h
+        args = (p(env._obs), p(env._rew), p(env._done), p(env._flags), p(env._term))
+        torch.cuda.synchronize()
+        for k in range(K):
+            assert lib.qs_step(h, p(pool[k % 64]), *args) == 0
+        env.sync()
+    torch.cuda.synchronize()
+    assert torch.equal(a._obs, b._obs) and torch.equal(a._rew, b._rew) and torch.equal(a._done, b._done)
+    np.testing.assert_array_equal(_full_state(a), _full_state(b))
+    assert a.step_counter == b.step_counter == K
+    a.close(); b.close()
+
+
+def test_private_queue_placement_guard_fails_loudly(qa, torch):
+    """the mode rests on every tile being stepped by the XCD that holds it; when a workgroup finds its tile owned by another
+    XCD it must touch nothing, and the next synchronising call must report it (tools/hsa_xcd_affinity_exp.py shows what
+    happens without the guard: 65 472 of 65 536 envs wrong)"""
+    n = 4096
+    env = qa.VecDockingEnv("docking-v0", num_envs=n, randomise=1, seed=9, init_range=qa.C3_INIT_RANGE, copy=False)
+    env.reset()
+    env.set_queue_mode(True)
+    acts = env.random_actions(2, step0=0)
+    env.step(acts[0])                                      # a good step: owners recorded
+    before = _full_state(env)
+    k_before = env.step_counter
+    lib = qa._lib.load()
+    assert lib.qs_debug_chain_poison_owner(env._h) == 0
+    import ctypes as C
+    p = lambda t: C.c_void_p(t.data_ptr())                 # noqa: E731
+    assert lib.qs_step(env._h, p(acts[1]), p(env._obs), p(env._rew), p(env._done), p(env._flags), p(env._term)) == 0
+    with pytest.raises(qa.QuadsimError, match="another XCD"):
+        env.sync()
+    np.testing.assert_array_equal(_full_state(env), before)         # the misplaced workgroups stored nothing
+    assert env.step_counter == k_before
+    env.step(acts[1])                                      # the handle recovers: owners are re-learnt after the HIP-side calls above
+    assert env.step_counter == k_before + 1
+    env.close()

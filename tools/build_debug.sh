@@ -4,5 +4,5 @@
 set -e
 cd "$(dirname "$0")/.."
 hipcc -std=c++20 -O3 -DQS_DEBUG -fno-slp-vectorize -ffp-contract=on --offload-arch=gfx950 -fPIC -shared -Wno-unused-result \
-    quadsim_amd/csrc/quadsim_hip.hip -o quadsim_amd/csrc/libquadsim_hip_dbg.so
+    quadsim_amd/csrc/quadsim_hip.hip -lhsa-runtime64 -o quadsim_amd/csrc/libquadsim_hip_dbg.so
 echo built quadsim_amd/csrc/libquadsim_hip_dbg.so

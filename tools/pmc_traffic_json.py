@@ -18,14 +18,27 @@ def mean(path, counter):
 
 k1, f_small, n1 = mean(base + "/FETCH_SIZE_65536", "FETCH_SIZE")
 _, w_small, _ = mean(base + "/WRITE_SIZE_65536", "WRITE_SIZE")
+try:
+    _, f_prv, n_prv = mean(base + "/FETCH_SIZE_65536_private", "FETCH_SIZE")
+    _, w_prv, _ = mean(base + "/WRITE_SIZE_65536_private", "WRITE_SIZE")
+except Exception:
+    f_prv = w_prv = None
 k2, f_big, _ = mean(base + "/FETCH_SIZE_2097152", "FETCH_SIZE")
 _, w_big, _ = mean(base + "/WRITE_SIZE_2097152", "WRITE_SIZE")
 n_big = 2097152
 fetch_ratio = f_big * 1024 / (176 * n_big)
-write_ratio = w_big * 1024 / (216 * n_big)
 corr = 1.0 / fetch_ratio
+write_ratio = w_big * 1024 / (216 * n_big)
 traffic = corr * f_small * 1024 + w_small * 1024
-json.dump({"kernel": k1.strip(), "envs": 65536, "dispatches_averaged": n1, "fetch_size_kib": f_small, "fetch_correction": corr,
+extra = {}
+if f_prv is not None:
+    t_prv = corr * f_prv * 1024 + w_prv * 1024
+    extra = {"private_queue": {"fetch_size_kib": f_prv, "write_size_kib": w_prv, "traffic_bytes_per_step": int(t_prv),
+                               "ratio": t_prv / (392 * 65536), "dispatches_averaged": n_prv,
+                               "note": "step launches without the end-of-kernel release: the tiles' state stays dirty in the XCDs' L2s, so "
+                                       "fewer bytes reach the memory side than the step moves algorithmically (the average includes the ~190 "
+                                       "fenced launches of bench.py's verification run)"}}
+json.dump({**extra, "kernel": k1.strip(), "envs": 65536, "dispatches_averaged": n1, "fetch_size_kib": f_small, "fetch_correction": corr,
            "write_size_kib": w_small, "traffic_bytes_per_step": int(traffic), "algorithmic_bytes_per_step": 392 * 65536,
            "ratio": traffic / (392 * 65536),
            "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes (tools/pmc.sh); FETCH_SIZE corrected by the "
