@@ -1511,10 +1511,20 @@ void groups_destroy(QsEnv *e)
 // the first step after HIP-side work waits for the handle's stream.  What the caller has in flight on HIP streams is not
 // ordered against the queue: inputs must be complete when qs_step is called, outputs are valid after qs_sync (pre-staged
 // actions, roll-outs; with a policy between the steps use the default mode).
+struct QsChainLane {                  // one private queue and the contiguous tile range it steps
+    hsa_queue_t *queue = nullptr;
+    char *kernargs = nullptr;
+    std::vector<uint64_t> slot_qidx;  // queue index of the packet that last used each kernarg slot
+    uint64_t issued = 0;              // step packets written so far
+    int64_t tile0 = 0, tile_end = 0;
+    hsa_signal_t done{};
+};
+
 struct QsChain {
     hsa_agent_t gpu{}, cpu{};
     hsa_amd_memory_pool_t kernarg_pool{};
-    hsa_queue_t *queue = nullptr;
+    std::vector<QsChainLane> lanes;
+    int requested = 0;                // the queue count qs_set_queue_mode was called with (lanes.size() may be smaller)
     hsa_executable_t exe{};
     hsa_code_object_reader_t reader{};
     bool have_exe = false, have_reader = false;
@@ -1522,11 +1532,7 @@ struct QsChain {
     uint64_t kernel_object = 0;
     uint32_t kernarg_size = 0, group_size = 0, private_size = 0;
     unsigned block = 0;
-    char *kernargs = nullptr;
     size_t stride = 0, slots = 0;
-    uint64_t issued = 0;              // step packets written so far
-    std::vector<uint64_t> slot_qidx;  // queue index of the packet that last used each kernarg slot
-    hsa_signal_t done{};
     unsigned char *d_owner = nullptr; // [tiles]
     unsigned *d_err = nullptr;
     bool kernargs_on_device = false;  // kernarg ring in BAR-mapped device memory (else: host memory, correct but slow)
@@ -1651,9 +1657,11 @@ void chain_close(QsEnv *e)
 {
     QsChain *c = e->chain;
     if (!c) return;
-    if (c->queue) hsa_queue_destroy(c->queue);
-    if (c->kernargs) hsa_amd_memory_pool_free(c->kernargs);
-    if (c->done.handle) hsa_signal_destroy(c->done);
+    for (QsChainLane &L : c->lanes) {
+        if (L.queue) hsa_queue_destroy(L.queue);
+        if (L.kernargs) hsa_amd_memory_pool_free(L.kernargs);
+        if (L.done.handle) hsa_signal_destroy(L.done);
+    }
     if (c->have_exe) hsa_executable_destroy(c->exe);
     if (c->have_reader) hsa_code_object_reader_destroy(c->reader);
     if (c->d_owner) (void)hipFree(c->d_owner);
@@ -1662,7 +1670,7 @@ void chain_close(QsEnv *e)
     e->chain = nullptr;
 }
 
-int chain_open(QsEnv *e)
+int chain_open(QsEnv *e, int nq)
 {
     if (e->cfg.kind == QS_KIND_HOVERING_V0) return fail(QS_ERR_INVALID, "qs_set_queue_mode: docking envs only");
     if (e->cfg.io_space != QS_IO_DEVICE) return fail(QS_ERR_INVALID, "qs_set_queue_mode: device buffers only");
@@ -1706,25 +1714,37 @@ int chain_open(QsEnv *e)
         HSA_TRY(hsa_executable_symbol_get_info(ks, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &c->group_size));
         HSA_TRY(hsa_executable_symbol_get_info(ks, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &c->private_size));
         if (c->kernarg_size < sizeof(StepArgs)) return fail(QS_ERR_HIP, "qs_set_queue_mode: kernel argument block is %u B, StepArgs %zu B", c->kernarg_size, sizeof(StepArgs));
-        HSA_TRY(hsa_queue_create(c->gpu, 4096, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &c->queue));
         c->stride = ((size_t)c->kernarg_size + 255) & ~size_t(255);
         // a small ring: a slot is rewritten only after its packet ran, and recently used kernarg lines are still in the caches
         // (4 096 slots: 5.43 us per step, 256: 5.27, 64 and 16: 5.24, 4: host-bound; profiles/r02/ab_experiments.txt, section E)
         c->slots = getenv("QS_CHAIN_SLOTS") ? (size_t)atoi(getenv("QS_CHAIN_SLOTS")) : 64;
         if (c->slots < 2 || c->slots > 4096) c->slots = 64;
-        c->slot_qidx.assign(c->slots, 0);
         DevPoolPick dp{c->cpu, {}, false};
         (void)hsa_amd_agent_iterate_memory_pools(c->gpu, chain_device_pool_cb, &dp);
-        if (dp.found) {
-            HSA_TRY(hsa_amd_memory_pool_allocate(dp.pool, c->stride * c->slots, 0, (void **)&c->kernargs));
-            HSA_TRY(hsa_amd_agents_allow_access(1, &c->cpu, nullptr, c->kernargs));
-            c->kernargs_on_device = true;
-        } else {
-            HSA_TRY(hsa_amd_memory_pool_allocate(c->kernarg_pool, c->stride * c->slots, 0, (void **)&c->kernargs));
-            HSA_TRY(hsa_amd_agents_allow_access(1, &c->gpu, nullptr, c->kernargs));
+        c->kernargs_on_device = dp.found;
+        // nq queues, each stepping a contiguous range of tiles (whole multiples of 8 tiles where possible: one per XCD)
+        std::vector<int64_t> cut{0};
+        for (int q = 1; q <= nq; ++q) {
+            int64_t t1 = q == nq ? e->tiles : ((e->tiles * q / nq) + 7) / 8 * 8;
+            if (t1 > e->tiles) t1 = e->tiles;
+            if (t1 > cut.back()) cut.push_back(t1);        // small handles: fewer, non-empty lanes
         }
-        memset(c->kernargs, 0, c->stride * c->slots);      // the hidden arguments behind StepArgs are never read: zeros
-        HSA_TRY(hsa_signal_create(0, 0, nullptr, &c->done));
+        c->lanes.resize(cut.size() - 1);
+        for (size_t q = 0; q + 1 < cut.size(); ++q) {
+            QsChainLane &L = c->lanes[q];
+            L.tile0 = cut[q]; L.tile_end = cut[q + 1];
+            HSA_TRY(hsa_queue_create(c->gpu, 4096, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &L.queue));
+            if (dp.found) {
+                HSA_TRY(hsa_amd_memory_pool_allocate(dp.pool, c->stride * c->slots, 0, (void **)&L.kernargs));
+                HSA_TRY(hsa_amd_agents_allow_access(1, &c->cpu, nullptr, L.kernargs));
+            } else {
+                HSA_TRY(hsa_amd_memory_pool_allocate(c->kernarg_pool, c->stride * c->slots, 0, (void **)&L.kernargs));
+                HSA_TRY(hsa_amd_agents_allow_access(1, &c->gpu, nullptr, L.kernargs));
+            }
+            memset(L.kernargs, 0, c->stride * c->slots);   // the hidden arguments behind StepArgs are never read: zeros
+            L.slot_qidx.assign(c->slots, 0);
+            HSA_TRY(hsa_signal_create(0, 0, nullptr, &L.done));
+        }
         HIP_TRY(hipMalloc((void **)&c->d_owner, (size_t)e->tiles));
         HIP_TRY(hipMalloc((void **)&c->d_err, sizeof(unsigned)));
         HIP_TRY(hipMemset(c->d_err, 0, sizeof(unsigned)));
@@ -1736,16 +1756,17 @@ int chain_open(QsEnv *e)
 }
 
 // one AQL packet: the step kernel (or, kernel_object == 0, a barrier packet) behind everything enqueued before it
-uint64_t chain_write_packet(QsChain *c, bool barrier_only, const void *kernarg, unsigned grid, int acquire, int release, bool signal)
+uint64_t chain_write_packet(QsChain *c, QsChainLane &L, bool barrier_only, const void *kernarg, unsigned grid, int acquire, int release,
+                            bool signal)
 {
-    const uint64_t idx = hsa_queue_add_write_index_relaxed(c->queue, 1);
-    while (idx - hsa_queue_load_read_index_scacquire(c->queue) >= c->queue->size) __builtin_ia32_pause();
-    void *slot = (char *)c->queue->base_address + (idx & (c->queue->size - 1)) * 64;
+    const uint64_t idx = hsa_queue_add_write_index_relaxed(L.queue, 1);
+    while (idx - hsa_queue_load_read_index_scacquire(L.queue) >= L.queue->size) __builtin_ia32_pause();
+    void *slot = (char *)L.queue->base_address + (idx & (L.queue->size - 1)) * 64;
     uint16_t header;
     if (barrier_only) {
         hsa_barrier_and_packet_t *p = (hsa_barrier_and_packet_t *)slot;
         memset((char *)p + 2, 0, 62);
-        p->completion_signal = signal ? c->done : hsa_signal_t{0};
+        p->completion_signal = signal ? L.done : hsa_signal_t{0};
         header = (HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE);
     } else {
         hsa_kernel_dispatch_packet_t *p = (hsa_kernel_dispatch_packet_t *)slot;
@@ -1758,13 +1779,13 @@ uint64_t chain_write_packet(QsChain *c, bool barrier_only, const void *kernarg, 
         p->kernel_object = c->kernel_object;
         p->kernarg_address = (void *)kernarg;
         p->reserved2 = 0;
-        p->completion_signal = signal ? c->done : hsa_signal_t{0};
+        p->completion_signal = signal ? L.done : hsa_signal_t{0};
         header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE);
     }
     header |= (1 << HSA_PACKET_HEADER_BARRIER) | (acquire << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
               (release << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
     __atomic_store_n((uint16_t *)slot, header, __ATOMIC_RELEASE);
-    hsa_signal_store_screlease(c->queue->doorbell_signal, (hsa_signal_value_t)idx);
+    hsa_signal_store_screlease(L.queue->doorbell_signal, (hsa_signal_value_t)idx);
     return idx;
 }
 
@@ -1773,9 +1794,12 @@ int chain_drain(QsEnv *e)
 {
     QsChain *c = e->chain;
     if (!c || !c->dirty) return QS_OK;
-    hsa_signal_store_relaxed(c->done, 1);
-    chain_write_packet(c, true, nullptr, 0, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_SYSTEM, true);
-    while (hsa_signal_wait_scacquire(c->done, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_ACTIVE) != 0) {}
+    for (QsChainLane &L : c->lanes) {
+        hsa_signal_store_relaxed(L.done, 1);
+        chain_write_packet(c, L, true, nullptr, 0, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_SYSTEM, true);
+    }
+    for (QsChainLane &L : c->lanes)
+        while (hsa_signal_wait_scacquire(L.done, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_ACTIVE) != 0) {}
     c->dirty = false;
     unsigned err = 0;
     HIP_TRY(hipMemcpy(&err, c->d_err, sizeof err, hipMemcpyDeviceToHost));
@@ -1799,23 +1823,34 @@ int chain_step(QsEnv *e, const StepArgs &A0)
     StepArgs A = A0;
     A.owner = c->d_owner;
     A.err = c->d_err;
-    // the slot about to be rewritten belongs to step `issued - slots`, queue packet q: that kernel has FINISHED once the packet
-    // behind it has been taken off the queue (every packet carries the barrier bit), i.e. once the read index has passed q + 1
-    const size_t sl = c->issued % c->slots;
-    if (c->issued >= c->slots)
-        while (hsa_queue_load_read_index_scacquire(c->queue) < c->slot_qidx[sl] + 2) __builtin_ia32_pause();
-    char *ka = c->kernargs + sl * c->stride;
-    memcpy(ka, &A, sizeof A);
-    if (c->kernargs_on_device) {
-        // posted writes through the BAR: read the last word back so that they have landed before the doorbell rings
-        __builtin_ia32_sfence();
-        (void)*(volatile uint32_t *)(ka + sizeof A - sizeof(uint32_t));
+    // all lanes' kernarg blocks first, ONE read-back behind them, then the packets: the read-back is a PCIe round trip
+    char *ka[8];
+    size_t slot[8];
+    const size_t nl = c->lanes.size();
+    for (size_t q = 0; q < nl; ++q) {
+        QsChainLane &L = c->lanes[q];
+        A.tile0 = L.tile0; A.tile_end = L.tile_end;
+        // the slot about to be rewritten belongs to step `issued - slots`, queue packet p: that kernel has FINISHED once the
+        // packet behind it has been taken off the queue (every packet carries the barrier bit): read index past p + 1
+        slot[q] = L.issued % c->slots;
+        if (L.issued >= c->slots)
+            while (hsa_queue_load_read_index_scacquire(L.queue) < L.slot_qidx[slot[q]] + 2) __builtin_ia32_pause();
+        ka[q] = L.kernargs + slot[q] * c->stride;
+        memcpy(ka[q], &A, sizeof A);
     }
-    const int64_t tiles = A.tile_end - A.tile0;
-    const unsigned grid = c->block == 2 * kTile ? (unsigned)(tiles * c->block)
-                                                : (unsigned)(((tiles + kBlock / kTile - 1) / (kBlock / kTile)) * kBlock);
-    c->slot_qidx[sl] = chain_write_packet(c, false, ka, grid, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_NONE, false);
-    ++c->issued;
+    if (c->kernargs_on_device) {
+        // posted writes through the BAR: reading the last word back makes sure they have landed before a doorbell rings
+        __builtin_ia32_sfence();
+        (void)*(volatile uint32_t *)(ka[nl - 1] + sizeof A - sizeof(uint32_t));
+    }
+    for (size_t q = 0; q < nl; ++q) {
+        QsChainLane &L = c->lanes[q];
+        const int64_t tiles = L.tile_end - L.tile0;
+        const unsigned grid = c->block == 2 * kTile ? (unsigned)(tiles * c->block)
+                                                    : (unsigned)(((tiles + kBlock / kTile - 1) / (kBlock / kTile)) * kBlock);
+        L.slot_qidx[slot[q]] = chain_write_packet(c, L, false, ka[q], grid, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_NONE, false);
+        ++L.issued;
+    }
     c->dirty = true;
     return QS_OK;
 }
@@ -2293,7 +2328,7 @@ int qs_step_groups(QsEnv *e, const float *actions, float *obs, float *reward, ui
 {
     Range rg_("qs_step_groups");
     CHECK_ENV_RAW(e);
-    if (e->groups.empty()) return qs_step_ex(e, actions, obs, reward, done, flags, terminal_obs, terminal_state);
+    if (e->groups.empty() || e->chain) return qs_step_ex(e, actions, obs, reward, done, flags, terminal_obs, terminal_state);
     if (!actions || !obs || !reward || !done) return fail(QS_ERR_INVALID, "qs_step_groups: actions, obs, reward and done are required");
     if (terminal_state && e->cfg.kind == QS_KIND_HOVERING_V0) return fail(QS_ERR_INVALID, "qs_step_groups: hovering-v0 has no terminal_state");
     if (e->main_dirty) { int rc = groups_fork(e); if (rc) return rc; }
@@ -2779,11 +2814,14 @@ int qs_runner_rollout_fast_blob_bytes(void) { return kAcFastBlobBytes; }
 int qs_set_queue_mode(QsEnv *e, int32_t mode)
 {
     CHECK_ENV(e);                                     // drains a queue that is being switched off
-    if (mode != QS_QUEUE_HIP_STREAM && mode != QS_QUEUE_PRIVATE) return fail(QS_ERR_INVALID, "qs_set_queue_mode: unknown mode %d", mode);
-    if (mode == QS_QUEUE_HIP_STREAM) { chain_close(e); return QS_OK; }
-    if (e->chain) return QS_OK;
+    if (mode < QS_QUEUE_HIP_STREAM || mode > 4) return fail(QS_ERR_INVALID, "qs_set_queue_mode: mode must be 0 (HIP stream) or 1..4 private queues");
+    if (e->chain && e->chain->requested == mode) return QS_OK;
+    chain_close(e);
+    if (mode == QS_QUEUE_HIP_STREAM) return QS_OK;
     HIP_TRY(hipStreamSynchronize(e->stream));
-    return chain_open(e);
+    int rc = chain_open(e, mode);
+    if (rc == QS_OK) e->chain->requested = mode;
+    return rc;
 }
 
 // Diagnostic (not in quadsim.h; tests only): pretend every tile is held by an XCD that does not exist, so that the placement
@@ -2802,7 +2840,7 @@ int qs_debug_chain_poison_owner(QsEnv *e)
 int qs_get_queue_mode(QsEnv *e, int32_t *mode)
 {
     if (!e || !mode) return fail(QS_ERR_INVALID, "qs_get_queue_mode: null argument");
-    *mode = e->chain ? QS_QUEUE_PRIVATE : QS_QUEUE_HIP_STREAM;
+    *mode = e->chain ? (int32_t)e->chain->lanes.size() : QS_QUEUE_HIP_STREAM;
     return QS_OK;
 }
 

@@ -345,16 +345,18 @@ def test_c_abi_argument_checks_of_the_new_entry_points(qa):
 
 
 # ---------------------------------------------------------------- private-queue mode (qs_set_queue_mode)
-@pytest.mark.parametrize("n,env_id,rnd,integ", [(65536, "docking-v0", 1, "frozen"), (1000, "docking-v2", 2, "frozen"),
-                                                (4096, "docking-v0", 0, "rk4"), (262144, "docking-v0", 1, "frozen")])
-def test_private_queue_chain_bit_identical_to_hip_stream(qa, torch, n, env_id, rnd, integ):
+@pytest.mark.parametrize("n,env_id,rnd,integ,queues", [(65536, "docking-v0", 1, "frozen", 1), (1000, "docking-v2", 2, "frozen", 1),
+                                                       (4096, "docking-v0", 0, "rk4", 2), (262144, "docking-v0", 1, "frozen", 1),
+                                                       (65536, "docking-v0", 1, "frozen", 2), (1000, "docking-v2", 2, "frozen", 3),
+                                                       (200, "docking-v0", 1, "frozen", 4), (131072, "docking-v2", 2, "frozen", 2)])
+def test_private_queue_chain_bit_identical_to_hip_stream(qa, torch, n, env_id, rnd, integ, queues):
     """step launches as hand-written AQL packets without the end-of-kernel release (the tile's state stays in its XCD's L2)
     == ordinary HIP launches, bit for bit: every step's outputs, terminal rows, the final state, the step counter; with
     main-stream calls (masked reset, set_state) in between, through both step kernels (split / serial), ragged tiles"""
     kw = dict(num_envs=n, randomise=rnd, seed=21, init_range=qa.C3_INIT_RANGE, mass_scale=(0.8, 1.2), inertia_scale=(0.8, 1.2),
               integrator=integ, copy=False)
     a, b = qa.VecDockingEnv(env_id, **kw), qa.VecDockingEnv(env_id, **kw)
-    b.set_queue_mode(True)
+    b.set_queue_mode(True, queues)
     assert b.queue_mode == "private" and a.queue_mode == "hip-stream"
     a.reset(); b.reset()
     t0 = np.zeros(n, np.float32); t0[::7] = 590.0
@@ -396,7 +398,7 @@ def test_private_queue_many_steps_and_raw_loop(qa, torch):
     kw = dict(num_envs=n, randomise=1, seed=5, init_range=qa.C3_INIT_RANGE, copy=False)
     a, b = qa.VecDockingEnv("docking-v0", **kw), qa.VecDockingEnv("docking-v0", **kw)
     a.reset(); b.reset()
-    b.set_queue_mode(True)
+    b.set_queue_mode(True, 2)
     pool = a.random_actions(64, step0=0)
     p = lambda t: C.c_void_p(t.data_ptr())                 # noqa: E731
     for env in (a, b):

@@ -169,6 +169,51 @@ int qsx_run_chain(uint32_t K, uint32_t grid_x, uint32_t block_x, int acquire_sco
     return 0;
 }
 
+// the same chain split over Q queues: queue q owns kernarg slots [q*per, (q+1)*per) (prepared by the caller with the tile range
+// of group q) and gets one packet per step; every queue ends with a system-scope release + signal
+int qsx_run_chain_multi(uint32_t K, uint32_t Q, uint32_t per, uint32_t grid_x, uint32_t block_x, int acquire_scope, int release_scope,
+                        double *elapsed_us)
+{
+    static hsa_queue_t *qs[8] = {nullptr};
+    static hsa_signal_t sig[8];
+    if (Q > 8) return -1;
+    for (uint32_t q = 0; q < Q; ++q)
+        if (!qs[q]) {
+            CK(hsa_queue_create(g.gpu, 4096, HSA_QUEUE_TYPE_SINGLE, nullptr, nullptr, UINT32_MAX, UINT32_MAX, &qs[q]));
+            CK(hsa_signal_create(1, 0, nullptr, &sig[q]));
+        }
+    for (uint32_t q = 0; q < Q; ++q) hsa_signal_store_relaxed(sig[q], 1);
+    auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t k = 0; k < K; ++k)
+        for (uint32_t q = 0; q < Q; ++q) {
+            hsa_queue_t *Qu = qs[q];
+            uint64_t idx = hsa_queue_add_write_index_relaxed(Qu, 1);
+            while (idx - hsa_queue_load_read_index_scacquire(Qu) >= Qu->size) {}
+            hsa_kernel_dispatch_packet_t *p = (hsa_kernel_dispatch_packet_t *)Qu->base_address + (idx & (Qu->size - 1));
+            const bool last = k + 1 == K;
+            p->setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
+            p->workgroup_size_x = (uint16_t)block_x; p->workgroup_size_y = 1; p->workgroup_size_z = 1;
+            p->grid_size_x = grid_x; p->grid_size_y = 1; p->grid_size_z = 1;
+            p->private_segment_size = g.private_size;
+            p->group_segment_size = g.group_size;
+            p->kernel_object = g.kernel_object;
+            p->kernarg_address = (char *)g.kernargs + (q * per + k % per) * g.kernarg_stride;
+            p->reserved2 = 0;
+            p->completion_signal = last ? sig[q] : hsa_signal_t{0};
+            const int acq = k == 0 ? 2 : acquire_scope;
+            const int rel = last ? 2 : release_scope;
+            uint16_t header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | (1 << HSA_PACKET_HEADER_BARRIER) |
+                              (acq << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) | (rel << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+            __atomic_store_n(&p->header, header, __ATOMIC_RELEASE);
+            hsa_signal_store_screlease(Qu->doorbell_signal, idx);
+        }
+    for (uint32_t q = 0; q < Q; ++q)
+        while (hsa_signal_wait_scacquire(sig[q], HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_ACTIVE) != 0) {}
+    auto t1 = std::chrono::steady_clock::now();
+    *elapsed_us = std::chrono::duration<double, std::micro>(t1 - t0).count();
+    return 0;
+}
+
 int qsx_close()
 {
     if (g.queue) hsa_queue_destroy(g.queue);
