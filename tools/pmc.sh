@@ -7,7 +7,7 @@ export TMPDIR=/tmp; cd /tmp
 X="--steps 200 --warmup 20 --min-timed-steps 200 --repeats 1 --action-pool 8 --no-cpu-baseline --no-extras --no-parity"
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $OUT/${C}_65536 -- python3 $R/bench.py --envs-per-gpu 65536 --queue-mode hip $X > $OUT/${C}_65536.log 2>&1 || echo "pass $C hip failed"
-  timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $OUT/${C}_65536_private -- python3 $R/bench.py --envs-per-gpu 65536 --queue-mode private $X > $OUT/${C}_65536_private.log 2>&1 || echo "pass $C private failed"
+  timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $OUT/${C}_65536_private -- python3 $R/bench.py --envs-per-gpu 65536 --queue-mode private --queues 1 $X > $OUT/${C}_65536_private.log 2>&1 || echo "pass $C private failed"
   timeout -k 10 300 rocprofv3 --pmc $C --output-format csv -d $OUT/${C}_2097152 -- python3 $R/bench.py --envs-per-gpu 2097152 --queue-mode hip $X > $OUT/${C}_2097152.log 2>&1 || echo "pass $C 2M failed"
 done
 cd $R
