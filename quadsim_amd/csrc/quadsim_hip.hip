@@ -1553,7 +1553,7 @@ namespace {
     } while (0)
 
 struct AgentPick {
-    uint32_t want_bdf;
+    uint32_t want_bdf, want_domain;
     int want_index, seen;
     hsa_agent_t gpu, cpu;
     bool have_gpu, have_cpu;
@@ -1566,10 +1566,15 @@ hsa_status_t chain_agent_cb(hsa_agent_t a, void *data)
     if (hsa_agent_get_info(a, HSA_AGENT_INFO_DEVICE, &t) != HSA_STATUS_SUCCESS) return HSA_STATUS_SUCCESS;
     if (t == HSA_DEVICE_TYPE_CPU && !p->have_cpu) { p->cpu = a; p->have_cpu = true; }
     if (t == HSA_DEVICE_TYPE_GPU) {
-        uint32_t bdf = 0;
-        const bool ok = hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf) == HSA_STATUS_SUCCESS;
-        // BDFID = bus << 8 | device << 3 | function
-        if ((ok && p->want_bdf != 0xffffffffu) ? bdf == p->want_bdf : p->seen == p->want_index) { p->gpu = a; p->have_gpu = true; }
+        uint32_t bdf = 0, dom = 0;
+        const bool ok = hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_BDFID, &bdf) == HSA_STATUS_SUCCESS &&
+                        hsa_agent_get_info(a, (hsa_agent_info_t)HSA_AMD_AGENT_INFO_DOMAIN, &dom) == HSA_STATUS_SUCCESS;
+        // the agent must be THE device of the handle: matched by PCI domain + bus/device/function (BDFID = bus << 8 | device << 3 |
+        // function); by ordinal only when HIP cannot name the device's PCI address
+        if (p->want_bdf != 0xffffffffu ? (ok && bdf == p->want_bdf && dom == p->want_domain) : p->seen == p->want_index) {
+            p->gpu = a;
+            p->have_gpu = true;
+        }
         ++p->seen;
     }
     return HSA_STATUS_SUCCESS;
@@ -1680,10 +1685,12 @@ int chain_open(QsEnv *e, int nq)
     auto body = [&]() -> int {
         HSA_TRY(hsa_init());
         char bus[32] = "";
-        AgentPick pick{0xffffffffu, e->cfg.device, 0, {}, {}, false, false};
+        AgentPick pick{0xffffffffu, 0, e->cfg.device, 0, {}, {}, false, false};
         unsigned dom = 0, b = 0, d = 0, f = 0;
-        if (hipDeviceGetPCIBusId(bus, sizeof bus, e->cfg.device) == hipSuccess && sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &f) == 4)
+        if (hipDeviceGetPCIBusId(bus, sizeof bus, e->cfg.device) == hipSuccess && sscanf(bus, "%x:%x:%x.%x", &dom, &b, &d, &f) == 4) {
             pick.want_bdf = (b << 8) | (d << 3) | f;
+            pick.want_domain = dom;
+        }
         HSA_TRY(hsa_iterate_agents(chain_agent_cb, &pick));
         if (!pick.have_gpu || !pick.have_cpu) return fail(QS_ERR_HIP, "qs_set_queue_mode: no HSA agent for device %d (%s)", e->cfg.device, bus);
         c->gpu = pick.gpu; c->cpu = pick.cpu;

@@ -1,6 +1,3 @@
-set -o pipefail
-R=$(pwd); OUT=$R/gpurun_out; mkdir -p $OUT
-timeout -k 10 900 python -m pytest tests -m gpu -q > $OUT/pytest_gpu_final.log 2>&1; echo "pytest rc=$?"; tail -3 $OUT/pytest_gpu_final.log
-timeout -k 10 300 python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -1
-bash tools/call_profiles_r02.sh 2>&1 | tail -6
-bash tools/call_bench_r02.sh 2>&1 | tail -14
+timeout -k 10 300 python -m pytest tests/test_gpu_groups_and_rollout.py -m gpu -q -x -k "private" 2>&1 | tail -3
+timeout -k 10 300 python bench.py --gpus 2 --backend gloo --steps 200 --no-extras --no-cpu-baseline --no-parity 2>/dev/null | python -c "
+import json,sys; d=json.loads(sys.stdin.read()); print(d['value']/1e9, d['config']['queue_mode'], d['config']['private_queues'], d['config']['queue_note'])"
