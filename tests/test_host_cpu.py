@@ -250,7 +250,8 @@ def test_bench_self_launches_ranks_without_a_launcher():
     if torch.cuda.is_available():
         pytest.skip("GPU present: covered by the gpu tier")
     assert "torch.distributed.run" not in p.stderr
-    assert p.stderr.count("needs an MI355X") == 2, p.stderr[-2000:]
+    # (the parent stops the other rank as soon as one has failed, so one or both children get to say it)
+    assert 1 <= p.stderr.count("needs an MI355X") <= 2, p.stderr[-2000:]
     assert p.returncode != 0
 
 
