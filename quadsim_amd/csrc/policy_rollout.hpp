@@ -257,6 +257,124 @@ __device__ __forceinline__ void split_bf16(float v, __bf16 &hi, __bf16 &lo)
     lo = (__bf16)(v - (float)hi);
 }
 
+// ReLU + hi/lo split of TWO accumulator values into one packed register each: 7 VALU instructions per pair (integer max
+// against 0 = ReLU without a canonicalising v_max; v_cvt_pk_bf16_f32 rounds both at once; the hi halves are widened back with
+// a shift and a mask; one packed subtract; one more v_cvt_pk) where the value-at-a-time form takes 14.  Same roundings.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void relu_split_pair(float v0, float v1, uint32_t &hi, uint32_t &lo)
+{
+    v0 = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v0), 0));
+    v1 = __builtin_bit_cast(float, max(__builtin_bit_cast(int, v1), 0));
+    const f32x2 v = {v0, v1};
+    hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2));
+    const f32x2 r = {v0 - __builtin_bit_cast(float, hi << 16), v1 - __builtin_bit_cast(float, hi & 0xffff0000u)};
+    lo = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+}
+__device__ __forceinline__ bf16x8 as_bf16x8(u32x4 w) { return __builtin_bit_cast(bf16x8, w); }
+
+#ifndef QS_WEAVE
+#define QS_WEAVE 1      // 0: layer-2 tiles one after the other (A/B reference), 1: hand-woven software pipeline
+#endif
+
+// Layer 2 of the split-bf16 heads: NT row tiles of 16 hidden units (one 128 x 128 layer = 8 tiles; the actor-critic runs its
+// two branches as one sequence of 16), each 48 MFMAs over the four env tiles of the wave, followed by ReLU + hi/lo split into
+// the B operands of the output layer (`out_step(pair, ch, cl)` after every second tile = one k-step of 32 hidden units).
+// The tiles run as a software pipeline: the MFMAs of tile s + 1 are issued around the split of tile s, which depends only on
+// tile s's accumulators -- the split's VALU work then rides in the issue shadow of the MFMAs (16 matrix cycles each, 4 to
+// issue) instead of standing between two MFMA runs.  hipcc does not weave the two streams by itself (at this register
+// pressure its scheduler falls back to source order, sched_group_barrier patterns included), so the source order IS the woven
+// order, pinned by scheduling barriers: MFMA m of tile s + 1 (order k-step | term | env tile, so that consecutive MFMAs use
+// different accumulators), then ONE instruction-sized piece of the split of tile s (pair m / 6, piece m % 6); the A fragments
+// of k-step p + 1 are requested while k-step p multiplies.  Runner, 65 536 envs: 17.1 -> 15.2 us per step.
+struct L2Tile { const bf16x8 *hi, *lo; const float *bias; };     // fragments [k-step][lane] of the tile, bias of its 16 rows
+
+template <int NT, class TileOf, class OutStep>
+__device__ __forceinline__ void mlp_layer2_split(const u32x4 (&bh)[4][4], const u32x4 (&bl)[4][4], int lane, int g, TileOf &&tile_of,
+                                                 OutStep &&out_step)
+{
+    auto h2_tile = [&](int s2, f32x4 (&h2)[4]) {
+        const L2Tile t = tile_of(s2);
+        const f32x4 bias = *reinterpret_cast<const f32x4 *>(t.bias + 4 * g);
+#pragma unroll
+        for (int et = 0; et < 4; ++et) h2[et] = bias;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const bf16x8 ah = t.hi[p * 64 + lane], al = t.lo[p * 64 + lane];
+#pragma unroll
+            for (int et = 0; et < 4; ++et) {
+                h2[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, as_bf16x8(bh[p][et]), h2[et], 0, 0, 0);
+                h2[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(bl[p][et]), h2[et], 0, 0, 0);
+                h2[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(bh[p][et]), h2[et], 0, 0, 0);
+            }
+        }
+    };
+    auto split_tile = [&](const f32x4 (&h2)[4], int half, u32x4 (&ch)[4], u32x4 (&cl)[4]) {
+#pragma unroll
+        for (int et = 0; et < 4; ++et)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                uint32_t h, l;
+                relu_split_pair(h2[et][2 * pr], h2[et][2 * pr + 1], h, l);
+                ch[et][2 * half + pr] = h;
+                cl[et][2 * half + pr] = l;
+            }
+    };
+    u32x4 ch[4], cl[4];                                    // split ReLU(H2) of a tile pair = one k-step of the output layer
+#if QS_WEAVE == 1
+    auto woven_stage = [&](int s2n, f32x4 (&hn)[4], const f32x4 (&hc)[4], int half) {
+        const L2Tile t = tile_of(s2n);
+        const bf16x8 *A2hi = t.hi + lane, *A2lo = t.lo + lane;
+        const f32x4 bias = *reinterpret_cast<const f32x4 *>(t.bias + 4 * g);
+        bf16x8 ah[2], al[2];
+        ah[0] = A2hi[0]; al[0] = A2lo[0];
+        float v0[8], v1[8], h0[8], h1[8];
+        uint32_t hu[8];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int m = 0; m < 48; ++m) {
+            const int p = m / 12, term = (m % 12) / 4, et = m % 4;
+            if (m % 12 == 0 && p < 3) { ah[(p + 1) & 1] = A2hi[(p + 1) * 64]; al[(p + 1) & 1] = A2lo[(p + 1) * 64]; }
+            const f32x4 cin = (p == 0 && term == 0) ? bias : hn[et];
+            hn[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(term == 0 ? al[p & 1] : ah[p & 1],
+                                                             as_bf16x8(term == 1 ? bl[p][et] : bh[p][et]), cin, 0, 0, 0);
+            const int pair = m / 6, piece = m % 6, se = pair >> 1, pr = pair & 1;
+            // (the element goes through a float temporary: __builtin_bit_cast applied to a vector-element lvalue reads element 0)
+            if (piece == 0) { const float x = hc[se][2 * pr]; v0[pair] = __builtin_bit_cast(float, max(__builtin_bit_cast(int, x), 0)); }
+            if (piece == 1) { const float x = hc[se][2 * pr + 1]; v1[pair] = __builtin_bit_cast(float, max(__builtin_bit_cast(int, x), 0)); }
+            if (piece == 2) { const f32x2 v = {v0[pair], v1[pair]}; hu[pair] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2)); }
+            if (piece == 3) h0[pair] = __builtin_bit_cast(float, hu[pair] << 16);
+            if (piece == 4) h1[pair] = __builtin_bit_cast(float, hu[pair] & 0xffff0000u);
+            if (piece == 5) {
+                const f32x2 r = {v0[pair] - h0[pair], v1[pair] - h1[pair]};
+                ch[se][2 * half + pr] = hu[pair];
+                cl[se][2 * half + pr] = __builtin_bit_cast(uint32_t, __builtin_convertvector(r, bf16x2));
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    f32x4 hcur[4], hnext[4];
+    h2_tile(0, hcur);
+#pragma unroll
+    for (int s2 = 0; s2 < NT; ++s2) {
+        if (s2 + 1 < NT) woven_stage(s2 + 1, hnext, hcur, s2 & 1);
+        else split_tile(hcur, s2 & 1, ch, cl);
+        if (s2 & 1) out_step(s2 >> 1, ch, cl);
+#pragma unroll
+        for (int et = 0; et < 4; ++et) hcur[et] = hnext[et];
+    }
+#else
+#pragma unroll
+    for (int s2 = 0; s2 < NT; ++s2) {
+        f32x4 h2[4];
+        h2_tile(s2, h2);
+        split_tile(h2, s2 & 1, ch, cl);
+        if (s2 & 1) out_step(s2 >> 1, ch, cl);
+    }
+#endif
+}
+
 __device__ __forceinline__ void mlp_actor_fast(const float obs[12], float act[4], const char *blob, float *sObs, float *sAct,
                                                int lane)
 {
@@ -287,7 +405,7 @@ __device__ __forceinline__ void mlp_actor_fast(const float obs[12], float act[4]
             xh[et][j] = h; xl[et][j] = l;
         }
     // ---- layer 1: 8 row tiles, ReLU, straight into split B operands of layer 2 (tiles 2p, 2p+1 -> k-step p)
-    bf16x8 bh[4][4], bl[4][4];      // [p][et]
+    u32x4 bh[4][4], bl[4][4];       // [p][et]: element j of the B operand = half (j & 1) of word j >> 1
 #pragma unroll
     for (int rt = 0; rt < 8; ++rt) {
         const f32x4 bias = *reinterpret_cast<const f32x4 *>(sB1 + 16 * rt + 4 * g);
@@ -299,11 +417,11 @@ __device__ __forceinline__ void mlp_actor_fast(const float obs[12], float act[4]
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl[et], acc, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh[et], acc, 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                __bf16 h, l;
-                split_bf16(fmaxf(acc[i], 0.0f), h, l);
-                bh[rt >> 1][et][4 * (rt & 1) + i] = h;
-                bl[rt >> 1][et][4 * (rt & 1) + i] = l;
+            for (int pr = 0; pr < 2; ++pr) {
+                uint32_t h, l;
+                relu_split_pair(acc[2 * pr], acc[2 * pr + 1], h, l);
+                bh[rt >> 1][et][2 * (rt & 1) + pr] = h;
+                bl[rt >> 1][et][2 * (rt & 1) + pr] = l;
             }
         }
     }
@@ -314,42 +432,17 @@ __device__ __forceinline__ void mlp_actor_fast(const float obs[12], float act[4]
 #pragma unroll
         for (int et = 0; et < 4; ++et) a3[et] = bias3;
     }
+    mlp_layer2_split<8>(bh, bl, lane, g,
+        [&](int nt) { return L2Tile{A2hi + nt * 4 * 64, A2lo + nt * 4 * 64, sB2 + 16 * nt}; },
+        [&](int q, const u32x4 (&ch)[4], const u32x4 (&cl)[4]) {
+            const bf16x8 wh = A3hi[q * 64 + lane], wl = A3lo[q * 64 + lane];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {                 // q = pair of layer-2 row tiles = k-step of layer 3
-        bf16x8 ch[4], cl[4];                      // split ReLU(H2) of the pair, per env tile
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            const int nt = 2 * q + half;
-            const f32x4 bias = *reinterpret_cast<const f32x4 *>(sB2 + 16 * nt + 4 * g);
-            f32x4 h2[4] = {bias, bias, bias, bias};
-#pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const bf16x8 ah = A2hi[(nt * 4 + p) * 64 + lane], al = A2lo[(nt * 4 + p) * 64 + lane];
-#pragma unroll
-                for (int et = 0; et < 4; ++et) {
-                    h2[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[p][et], h2[et], 0, 0, 0);
-                    h2[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[p][et], h2[et], 0, 0, 0);
-                    h2[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[p][et], h2[et], 0, 0, 0);
-                }
+            for (int et = 0; et < 4; ++et) {
+                a3[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, as_bf16x8(ch[et]), a3[et], 0, 0, 0);
+                a3[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, as_bf16x8(cl[et]), a3[et], 0, 0, 0);
+                a3[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, as_bf16x8(ch[et]), a3[et], 0, 0, 0);
             }
-#pragma unroll
-            for (int et = 0; et < 4; ++et)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    __bf16 h, l;
-                    split_bf16(fmaxf(h2[et][i], 0.0f), h, l);
-                    ch[et][4 * half + i] = h;
-                    cl[et][4 * half + i] = l;
-                }
-        }
-        const bf16x8 wh = A3hi[q * 64 + lane], wl = A3lo[q * 64 + lane];
-#pragma unroll
-        for (int et = 0; et < 4; ++et) {
-            a3[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ch[et], a3[et], 0, 0, 0);
-            a3[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, cl[et], a3[et], 0, 0, 0);
-            a3[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ch[et], a3[et], 0, 0, 0);
-        }
-    }
+        });
     if (g == 0) {
 #pragma unroll
         for (int et = 0; et < 4; ++et) *reinterpret_cast<f32x4 *>(sAct + (16 * et + c) * 4) = a3[et];
@@ -394,7 +487,7 @@ __device__ __forceinline__ void mlp_actor_critic_fast(const float obs[12], float
     for (int s = 0; s < 3; ++s)
 #pragma unroll
         for (int et = 0; et < 4; ++et) xb[s][et] = stage[(4 * s + g) * 64 + 16 * et + c];
-    bf16x8 bh[4][4], bl[4][4];      // [p][et]
+    u32x4 bh[4][4], bl[4][4];       // [p][et]: element j of the B operand = word j >> 1
 #pragma unroll
     for (int rt = 0; rt < 8; ++rt) {
         const f32x4 bias = *reinterpret_cast<const f32x4 *>(sB1 + 16 * rt + 4 * g);
@@ -407,11 +500,11 @@ __device__ __forceinline__ void mlp_actor_critic_fast(const float obs[12], float
 #pragma unroll
             for (int s = 0; s < 3; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], xb[s][et], acc, 0, 0, 0);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                __bf16 h, l;
-                split_bf16(fmaxf(acc[i], 0.0f), h, l);
-                bh[rt >> 1][et][4 * (rt & 1) + i] = h;
-                bl[rt >> 1][et][4 * (rt & 1) + i] = l;
+            for (int pr = 0; pr < 2; ++pr) {
+                uint32_t h, l;
+                relu_split_pair(acc[2 * pr], acc[2 * pr + 1], h, l);
+                bh[rt >> 1][et][2 * (rt & 1) + pr] = h;
+                bl[rt >> 1][et][2 * (rt & 1) + pr] = l;
             }
         }
     }
@@ -421,58 +514,31 @@ __device__ __forceinline__ void mlp_actor_critic_fast(const float obs[12], float
 #pragma unroll
         for (int et = 0; et < 4; ++et) a3[et] = bias3;
     }
-    const bf16x8 zero8 = {};
-#pragma unroll
-    for (int br = 0; br < 2; ++br) {                       // 0: policy branch -> rows 0..3, 1: value branch -> row 4
-        const bf16x8 *A2hi = reinterpret_cast<const bf16x8 *>(blob + kAcFastA2 + br * 65536);
-        const bf16x8 *A2lo = reinterpret_cast<const bf16x8 *>(blob + kAcFastA2 + br * 65536 + 32768);
-        const float *sB2 = br ? sB2v : sB2p;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {                      // pair of layer-2 row tiles = k-step of the output layer
-            bf16x8 ch[4], cl[4];
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                const int nt = 2 * q + half;
-                const f32x4 bias = *reinterpret_cast<const f32x4 *>(sB2 + 16 * nt + 4 * g);
-                f32x4 h2[4] = {bias, bias, bias, bias};
-#pragma unroll
-                for (int p = 0; p < 4; ++p) {
-                    const bf16x8 ah = A2hi[(nt * 4 + p) * 64 + lane], al = A2lo[(nt * 4 + p) * 64 + lane];
-#pragma unroll
-                    for (int et = 0; et < 4; ++et) {
-                        h2[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bh[p][et], h2[et], 0, 0, 0);
-                        h2[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bl[p][et], h2[et], 0, 0, 0);
-                        h2[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bh[p][et], h2[et], 0, 0, 0);
-                    }
-                }
-#pragma unroll
-                for (int et = 0; et < 4; ++et)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        __bf16 h, l;
-                        split_bf16(fmaxf(h2[et][i], 0.0f), h, l);
-                        ch[et][4 * half + i] = h;
-                        cl[et][4 * half + i] = l;
-                    }
-            }
-            bf16x8 wh = zero8, wl = zero8;
-            if (br == 0) {
-                if (c < 4) {
-                    wh = reinterpret_cast<const bf16x8 *>(blob + kAcFastA3p)[(q * 4 + c) * 4 + g];
-                    wl = reinterpret_cast<const bf16x8 *>(blob + kAcFastA3p + 1024)[(q * 4 + c) * 4 + g];
-                }
-            } else if (c == 4) {
-                wh = reinterpret_cast<const bf16x8 *>(blob + kAcFastA3v)[q * 4 + g];
-                wl = reinterpret_cast<const bf16x8 *>(blob + kAcFastA3v + 256)[q * 4 + g];
-            }
+    // the 16 layer-2 row tiles: s2 = 8 br + nt; br 0: policy branch -> output rows 0..3, br 1: value branch -> row 4
+    mlp_layer2_split<16>(bh, bl, lane, g,
+        [&](int s2) {
+            const int br = s2 >> 3, nt = s2 & 7;
+            return L2Tile{reinterpret_cast<const bf16x8 *>(blob + kAcFastA2 + br * 65536) + nt * 4 * 64,
+                          reinterpret_cast<const bf16x8 *>(blob + kAcFastA2 + br * 65536 + 32768) + nt * 4 * 64,
+                          (br ? sB2v : sB2p) + 16 * nt};
+        },
+        [&](int pair, const u32x4 (&ch)[4], const u32x4 (&cl)[4]) {
+            // output-layer A fragments: rows 0..3 (policy) / row 4 (value) hold weights, every other row of the 16-row tile
+            // reads 16 zero bytes (slots 8..11 of the padded b3) -- an address select, no branch in the MFMA stream
+            const int br = pair >> 2, q = pair & 3;
+            const bf16x8 *ph = br == 0 ? reinterpret_cast<const bf16x8 *>(blob + kAcFastA3p) + (q * 4 + (c & 3)) * 4 + g
+                                       : reinterpret_cast<const bf16x8 *>(blob + kAcFastA3v) + q * 4 + g;
+            const bf16x8 *pl = br == 0 ? ph + 1024 / 16 : ph + 256 / 16;
+            const bool row_live = br == 0 ? c < 4 : c == 4;
+            const bf16x8 *pz = reinterpret_cast<const bf16x8 *>(sB3 + 8);
+            const bf16x8 wh = *(row_live ? ph : pz), wl = *(row_live ? pl : pz);
 #pragma unroll
             for (int et = 0; et < 4; ++et) {
-                a3[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, ch[et], a3[et], 0, 0, 0);
-                a3[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, cl[et], a3[et], 0, 0, 0);
-                a3[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, ch[et], a3[et], 0, 0, 0);
+                a3[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, as_bf16x8(ch[et]), a3[et], 0, 0, 0);
+                a3[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, as_bf16x8(cl[et]), a3[et], 0, 0, 0);
+                a3[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, as_bf16x8(ch[et]), a3[et], 0, 0, 0);
             }
-        }
-    }
+        });
     if (g == 0) {
 #pragma unroll
         for (int et = 0; et < 4; ++et) *reinterpret_cast<f32x4 *>(stage + (16 * et + c) * 8) = a3[et];

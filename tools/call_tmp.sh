@@ -1,3 +1,9 @@
-R=$(pwd)
-QUADSIM_HIP_LIB=$R/quadsim_amd/csrc/libquadsim_hip_dbg.so timeout -k 10 900 python -m pytest tests -m gpu -q 2>&1 | tail -3
-QUADSIM_HIP_LIB=$R/quadsim_amd/csrc/libquadsim_hip_dbg.so timeout -k 10 600 python tools/soak_shape_debug.py 2>&1 | tail -4
+#!/bin/bash
+cd /root/repo; mkdir -p gpurun_out
+{
+timeout -k 10 300 python -m pytest tests -x -q -m gpu -k "fast or bf16 or runner or policy" 2>&1 | tail -3
+for i in 1 2; do for L in libqs_base.so libquadsim_hip.so; do
+  QUADSIM_HIP_LIB=/root/repo/quadsim_amd/csrc/$L timeout -k 10 200 python tools/ab_policy.py 2>&1 | tail -1
+done; done
+} > gpurun_out/ab_weave.txt 2>&1
+cat gpurun_out/ab_weave.txt
