@@ -290,29 +290,31 @@ __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 w) { return __builtin_bit_cast
 // of k-step p + 1 are requested while k-step p multiplies.  Runner, 65 536 envs: 17.1 -> 15.2 us per step.
 struct L2Tile { const bf16x8 *hi, *lo; const float *bias; };     // fragments [k-step][lane] of the tile, bias of its 16 rows
 
-template <int NT, class TileOf, class OutStep>
+// NET / E0: the pass covers env tiles E0 .. E0 + NET - 1 of the wave's four (a 2-tile pass halves the working set of
+// accumulators and output-layer operands; the role-split runner's matrix waves run two such passes per branch).
+template <int NT, int NET, int E0, class TileOf, class OutStep>
 __device__ __forceinline__ void mlp_layer2_split(const u32x4 (&bh)[4][4], const u32x4 (&bl)[4][4], int lane, int g, TileOf &&tile_of,
                                                  OutStep &&out_step)
 {
-    auto h2_tile = [&](int s2, f32x4 (&h2)[4]) {
+    auto h2_tile = [&](int s2, f32x4 (&h2)[NET]) {
         const L2Tile t = tile_of(s2);
         const f32x4 bias = *reinterpret_cast<const f32x4 *>(t.bias + 4 * g);
 #pragma unroll
-        for (int et = 0; et < 4; ++et) h2[et] = bias;
+        for (int et = 0; et < NET; ++et) h2[et] = bias;
 #pragma unroll
         for (int p = 0; p < 4; ++p) {
             const bf16x8 ah = t.hi[p * 64 + lane], al = t.lo[p * 64 + lane];
 #pragma unroll
-            for (int et = 0; et < 4; ++et) {
-                h2[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, as_bf16x8(bh[p][et]), h2[et], 0, 0, 0);
-                h2[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(bl[p][et]), h2[et], 0, 0, 0);
-                h2[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(bh[p][et]), h2[et], 0, 0, 0);
+            for (int et = 0; et < NET; ++et) {
+                h2[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, as_bf16x8(bh[p][E0 + et]), h2[et], 0, 0, 0);
+                h2[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(bl[p][E0 + et]), h2[et], 0, 0, 0);
+                h2[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, as_bf16x8(bh[p][E0 + et]), h2[et], 0, 0, 0);
             }
         }
     };
-    auto split_tile = [&](const f32x4 (&h2)[4], int half, u32x4 (&ch)[4], u32x4 (&cl)[4]) {
+    auto split_tile = [&](const f32x4 (&h2)[NET], int half, u32x4 (&ch)[NET], u32x4 (&cl)[NET]) {
 #pragma unroll
-        for (int et = 0; et < 4; ++et)
+        for (int et = 0; et < NET; ++et)
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {
                 uint32_t h, l;
@@ -321,24 +323,24 @@ __device__ __forceinline__ void mlp_layer2_split(const u32x4 (&bh)[4][4], const 
                 cl[et][2 * half + pr] = l;
             }
     };
-    u32x4 ch[4], cl[4];                                    // split ReLU(H2) of a tile pair = one k-step of the output layer
+    u32x4 ch[NET], cl[NET];                                // split ReLU(H2) of a tile pair = one k-step of the output layer
 #if QS_WEAVE == 1
-    auto woven_stage = [&](int s2n, f32x4 (&hn)[4], const f32x4 (&hc)[4], int half) {
+    auto woven_stage = [&](int s2n, f32x4 (&hn)[NET], const f32x4 (&hc)[NET], int half) {
         const L2Tile t = tile_of(s2n);
         const bf16x8 *A2hi = t.hi + lane, *A2lo = t.lo + lane;
         const f32x4 bias = *reinterpret_cast<const f32x4 *>(t.bias + 4 * g);
         bf16x8 ah[2], al[2];
         ah[0] = A2hi[0]; al[0] = A2lo[0];
-        float v0[8], v1[8], h0[8], h1[8];
-        uint32_t hu[8];
+        float v0[2 * NET], v1[2 * NET], h0[2 * NET], h1[2 * NET];
+        uint32_t hu[2 * NET];
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int m = 0; m < 48; ++m) {
-            const int p = m / 12, term = (m % 12) / 4, et = m % 4;
-            if (m % 12 == 0 && p < 3) { ah[(p + 1) & 1] = A2hi[(p + 1) * 64]; al[(p + 1) & 1] = A2lo[(p + 1) * 64]; }
+        for (int m = 0; m < 12 * NET; ++m) {
+            const int p = m / (3 * NET), term = (m % (3 * NET)) / NET, et = m % NET;
+            if (m % (3 * NET) == 0 && p < 3) { ah[(p + 1) & 1] = A2hi[(p + 1) * 64]; al[(p + 1) & 1] = A2lo[(p + 1) * 64]; }
             const f32x4 cin = (p == 0 && term == 0) ? bias : hn[et];
             hn[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(term == 0 ? al[p & 1] : ah[p & 1],
-                                                             as_bf16x8(term == 1 ? bl[p][et] : bh[p][et]), cin, 0, 0, 0);
+                                                             as_bf16x8(term == 1 ? bl[p][E0 + et] : bh[p][E0 + et]), cin, 0, 0, 0);
             const int pair = m / 6, piece = m % 6, se = pair >> 1, pr = pair & 1;
             // (the element goes through a float temporary: __builtin_bit_cast applied to a vector-element lvalue reads element 0)
             if (piece == 0) { const float x = hc[se][2 * pr]; v0[pair] = __builtin_bit_cast(float, max(__builtin_bit_cast(int, x), 0)); }
@@ -354,7 +356,7 @@ __device__ __forceinline__ void mlp_layer2_split(const u32x4 (&bh)[4][4], const 
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    f32x4 hcur[4], hnext[4];
+    f32x4 hcur[NET], hnext[NET];
     h2_tile(0, hcur);
 #pragma unroll
     for (int s2 = 0; s2 < NT; ++s2) {
@@ -362,12 +364,12 @@ __device__ __forceinline__ void mlp_layer2_split(const u32x4 (&bh)[4][4], const 
         else split_tile(hcur, s2 & 1, ch, cl);
         if (s2 & 1) out_step(s2 >> 1, ch, cl);
 #pragma unroll
-        for (int et = 0; et < 4; ++et) hcur[et] = hnext[et];
+        for (int et = 0; et < NET; ++et) hcur[et] = hnext[et];
     }
 #else
 #pragma unroll
     for (int s2 = 0; s2 < NT; ++s2) {
-        f32x4 h2[4];
+        f32x4 h2[NET];
         h2_tile(s2, h2);
         split_tile(h2, s2 & 1, ch, cl);
         if (s2 & 1) out_step(s2 >> 1, ch, cl);
@@ -432,7 +434,7 @@ __device__ __forceinline__ void mlp_actor_fast(const float obs[12], float act[4]
 #pragma unroll
         for (int et = 0; et < 4; ++et) a3[et] = bias3;
     }
-    mlp_layer2_split<8>(bh, bl, lane, g,
+    mlp_layer2_split<8, 4, 0>(bh, bl, lane, g,
         [&](int nt) { return L2Tile{A2hi + nt * 4 * 64, A2lo + nt * 4 * 64, sB2 + 16 * nt}; },
         [&](int q, const u32x4 (&ch)[4], const u32x4 (&cl)[4]) {
             const bf16x8 wh = A3hi[q * 64 + lane], wl = A3lo[q * 64 + lane];
@@ -515,7 +517,7 @@ __device__ __forceinline__ void mlp_actor_critic_fast(const float obs[12], float
         for (int et = 0; et < 4; ++et) a3[et] = bias3;
     }
     // the 16 layer-2 row tiles: s2 = 8 br + nt; br 0: policy branch -> output rows 0..3, br 1: value branch -> row 4
-    mlp_layer2_split<16>(bh, bl, lane, g,
+    mlp_layer2_split<16, 4, 0>(bh, bl, lane, g,
         [&](int s2) {
             const int br = s2 >> 3, nt = s2 & 7;
             return L2Tile{reinterpret_cast<const bf16x8 *>(blob + kAcFastA2 + br * 65536) + nt * 4 * 64,
@@ -552,6 +554,149 @@ __device__ __forceinline__ void mlp_actor_critic_fast(const float obs[12], float
     out[0] = av[0]; out[1] = av[1]; out[2] = av[2]; out[3] = av[3];
     out[4] = stage[lane * 8 + 4];
     __builtin_amdgcn_wave_barrier();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Role-split runner (k_runner_split): the heads cut into the pieces a MATRIX wave runs while an ENV wave of the same tile
+// steps the environments.  ac_fast_layer1: shared layer for the wave's 64 envs (observations read from the tile's LDS
+// stage, [k][env]), result = the B operands of BOTH 128 x 128 branches, kept in registers.  ac_fast_branch<BR>: one branch
+// (0 policy -> rows 0..3 of a3, 1 value -> row 4) in two passes of two env tiles (256 registers per wave at two waves per
+// SIMD: a four-tile pass does not fit next to the 128 operand registers).
+__device__ __forceinline__ void ac_fast_layer1(const char *blob, const float *stage, int lane, u32x4 (&bh)[4][4], u32x4 (&bl)[4][4])
+{
+    const float *sW1 = reinterpret_cast<const float *>(blob + kAcFastW1);
+    const float *sB1 = reinterpret_cast<const float *>(blob + kAcFastB);
+    const int c = lane & 15, g = lane >> 4;
+    float xb[3][4];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int et = 0; et < 4; ++et) xb[s][et] = stage[(4 * s + g) * 64 + 16 * et + c];
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt) {
+        const f32x4 bias = *reinterpret_cast<const f32x4 *>(sB1 + 16 * rt + 4 * g);
+        float a[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) a[s] = sW1[(16 * rt + c) * kLdW1 + 4 * s + g];
+#pragma unroll
+        for (int et = 0; et < 4; ++et) {
+            f32x4 acc = bias;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], xb[s][et], acc, 0, 0, 0);
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                uint32_t h, l;
+                relu_split_pair(acc[2 * pr], acc[2 * pr + 1], h, l);
+                bh[rt >> 1][et][2 * (rt & 1) + pr] = h;
+                bl[rt >> 1][et][2 * (rt & 1) + pr] = l;
+            }
+        }
+    }
+}
+
+#ifndef QS_SPLIT_NET
+#define QS_SPLIT_NET 2      // env tiles per layer-2 pass of a matrix wave
+#endif
+template <int BR, int E0>
+__device__ __forceinline__ void ac_fast_branch_pass(const char *blob, const u32x4 (&bh)[4][4], const u32x4 (&bl)[4][4], int lane,
+                                                    f32x4 (&a3)[4])
+{
+    const float *sB1 = reinterpret_cast<const float *>(blob + kAcFastB);
+    const float *sB2 = sB1 + (1 + BR) * kHid, *sB3 = sB1 + 3 * kHid;
+    const int c = lane & 15, g = lane >> 4;
+    mlp_layer2_split<8, QS_SPLIT_NET, E0>(bh, bl, lane, g,
+        [&](int nt) {
+            return L2Tile{reinterpret_cast<const bf16x8 *>(blob + kAcFastA2 + BR * 65536) + nt * 4 * 64,
+                          reinterpret_cast<const bf16x8 *>(blob + kAcFastA2 + BR * 65536 + 32768) + nt * 4 * 64, sB2 + 16 * nt};
+        },
+        [&](int q, const u32x4 (&ch)[QS_SPLIT_NET], const u32x4 (&cl)[QS_SPLIT_NET]) {
+            const bf16x8 *ph = BR == 0 ? reinterpret_cast<const bf16x8 *>(blob + kAcFastA3p) + (q * 4 + (c & 3)) * 4 + g
+                                       : reinterpret_cast<const bf16x8 *>(blob + kAcFastA3v) + q * 4 + g;
+            const bf16x8 *pl = BR == 0 ? ph + 1024 / 16 : ph + 256 / 16;
+            const bool row_live = BR == 0 ? c < 4 : c == 4;
+            const bf16x8 *pz = reinterpret_cast<const bf16x8 *>(sB3 + 8);
+            const bf16x8 wh = *(row_live ? ph : pz), wl = *(row_live ? pl : pz);
+#pragma unroll
+            for (int et = 0; et < QS_SPLIT_NET; ++et) {
+                a3[E0 + et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, as_bf16x8(ch[et]), a3[E0 + et], 0, 0, 0);
+                a3[E0 + et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, as_bf16x8(cl[et]), a3[E0 + et], 0, 0, 0);
+                a3[E0 + et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, as_bf16x8(ch[et]), a3[E0 + et], 0, 0, 0);
+            }
+        });
+}
+
+template <int BR>
+__device__ __forceinline__ void ac_fast_branch(const char *blob, const u32x4 (&bh)[4][4], const u32x4 (&bl)[4][4], int lane, f32x4 (&a3)[4])
+{
+    const float *sB3 = reinterpret_cast<const float *>(blob + kAcFastB) + 3 * kHid;
+    const f32x4 bias3 = *reinterpret_cast<const f32x4 *>(sB3 + 4 * (lane >> 4));
+#pragma unroll
+    for (int et = 0; et < 4; ++et) a3[et] = bias3;
+    ac_fast_branch_pass<BR, 0>(blob, bh, bl, lane, a3);
+    if (QS_SPLIT_NET == 2) ac_fast_branch_pass<BR, QS_SPLIT_NET == 2 ? 2 : 0>(blob, bh, bl, lane, a3);
+}
+
+// The exact-float32 heads in the same two pieces: identical MFMA sequences per accumulator as mlp_actor_critic -- the one
+// difference is that each branch starts its own accumulators from the output bias instead of sharing one set, which adds the
+// other branch's exact zeros in a different place (the same sums bit for bit).
+__device__ __forceinline__ void ac_exact_layer1(const AcLds &L, const float *stage, int lane, f32x4 (&h1)[8][4])
+{
+    const int c = lane & 15, g = lane >> 4;
+    float xb[3][4];
+#pragma unroll
+    for (int s = 0; s < 3; ++s)
+#pragma unroll
+        for (int et = 0; et < 4; ++et) xb[s][et] = stage[(4 * s + g) * 64 + 16 * et + c];
+#pragma unroll
+    for (int rt = 0; rt < 8; ++rt) {
+        const f32x4 bias = *reinterpret_cast<const f32x4 *>(L.B1 + 16 * rt + 4 * g);
+        float a[3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) a[s] = L.W1[(16 * rt + c) * kLdW1 + 4 * s + g];
+#pragma unroll
+        for (int et = 0; et < 4; ++et) {
+            f32x4 acc = bias;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], xb[s][et], acc, 0, 0, 0);
+            h1[rt][et] = relu4(acc);
+        }
+    }
+}
+
+template <int BR>
+__device__ __forceinline__ void ac_exact_branch(const AcLds &L, const f32x4 (&h1)[8][4], int lane, f32x4 (&a3)[4])
+{
+    const int c = lane & 15, g = lane >> 4;
+    const f32x4 bias3 = *reinterpret_cast<const f32x4 *>(L.B3 + 4 * g);
+#pragma unroll
+    for (int et = 0; et < 4; ++et) a3[et] = bias3;
+    const float *W2 = BR ? L.W2v : L.W2p;
+    const float *B2 = BR ? L.B2v : L.B2p;
+    // output-layer A operand: row c of the 16-row tile; only rows 0..3 (policy) / row 4 (value) are non-zero -- every other
+    // row reads 16 zero bytes (slots 8..11 of the padded b3): an address select, no branch in the MFMA stream
+    const bool row_live = BR == 0 ? c < 4 : c == 4;
+    const float *w3row = BR == 0 ? L.W3p + (c & 3) * kLdW + 4 * g : L.W3v + 4 * g;
+#pragma unroll
+    for (int nt = 0; nt < 8; ++nt) {
+        const f32x4 bias = *reinterpret_cast<const f32x4 *>(B2 + 16 * nt + 4 * g);
+        f32x4 h2[4] = {bias, bias, bias, bias};
+#pragma unroll
+        for (int rt = 0; rt < 8; ++rt) {
+            const f32x4 w = *reinterpret_cast<const f32x4 *>(W2 + (16 * nt + c) * kLdW + 16 * rt + 4 * g);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int et = 0; et < 4; ++et)
+                    h2[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i], h1[rt][et][i], h2[et], 0, 0, 0);
+        }
+        const f32x4 w3 = *reinterpret_cast<const f32x4 *>(row_live ? w3row + 16 * nt : L.B3 + 8);
+#pragma unroll
+        for (int et = 0; et < 4; ++et) {
+            const f32x4 r = relu4(h2[et]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a3[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[i], r[i], a3[et], 0, 0, 0);
+        }
+    }
 }
 
 }  // namespace qs

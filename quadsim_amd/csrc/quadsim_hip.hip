@@ -65,10 +65,26 @@ __device__ unsigned long long g_qs_stamp_cap = 0;
             if (ix_ + 8 <= g_qs_stamp_cap) for (int j_ = 0; j_ < 8; ++j_) g_qs_stamps[ix_ + j_] = stamp_[j_];    \
         }                                                                                                       \
     } while (0)
+// runner kernels: phase durations summed over the T steps of one launch, [tile][role][8] words
+#define QS_PHASE_DECL unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t_ = __builtin_amdgcn_s_memrealtime(); \
+    const unsigned long long ph_c0_ = __builtin_amdgcn_s_memtime(), ph_r0_ = ph_t_
+#define QS_PHASE(slot) do { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); ph_[slot] += n_ - ph_t_; ph_t_ = n_; } while (0)
+#define QS_PHASE_FLUSH(role_)                                                                                   \
+    do {                                                                                                        \
+        ph_[6] = __builtin_amdgcn_s_memtime() - ph_c0_;          /* shader clocks ... */                         \
+        ph_[7] = __builtin_amdgcn_s_memrealtime() - ph_r0_;      /* ... per 10 ns ticks = the clock frequency */ \
+        if (lane == 0 && g_qs_stamps) {                                                                         \
+            const unsigned long long ix_ = (unsigned long long)tile * 16ull + 8 * (role_);                      \
+            if (ix_ + 8 <= g_qs_stamp_cap) for (int j_ = 0; j_ < 8; ++j_) g_qs_stamps[ix_ + j_] = ph_[j_];       \
+        }                                                                                                       \
+    } while (0)
 #else
 #define QS_STAMP_DECL ((void)0)
 #define QS_STAMP_AT(slot) ((void)0)
 #define QS_STAMP_FLUSH() ((void)0)
+#define QS_PHASE_DECL ((void)0)
+#define QS_PHASE(slot) ((void)0)
+#define QS_PHASE_FLUSH(role_) ((void)0)
 #endif
 
 // Store flavour of the step kernels' state rows and outputs: non-temporal (`nt`).  Every byte a step writes is consumed by a
@@ -793,6 +809,195 @@ __global__ __launch_bounds__(kBlock, 1) void k_runner_rollout(StepArgs A, Runner
         store_env(A.st, tile, lane, e);
         if (PARAMS && RMODE == 2) store_par(A.par, tile, lane, P);
         step_counter_end(A, tile, lane, k0);
+    }
+}
+
+// Role-split variant of the Runner kernel: one workgroup = four tiles = EIGHT waves.  Waves 0..3 ("matrix" role,
+// one per SIMD) only evaluate the networks, waves 4..7 ("env" role, wave 4 + i next to wave i) own the environment state of
+// the same four tiles: sampling, neglogp, env.step, every mb_* store except the values.  Per step and tile
+//   env wave:     obs -> LDS | draw N(0,1)            -> #b -> sample, neglogp, stores, env.step, new obs -> LDS  -> #a
+//   matrix wave:  -> #a -> layer 1, policy branch, means -> LDS -> #b -> value branch, store value
+// so the value branch (almost half of a step's MFMAs) and the env step (VALU) run at the same time on the same SIMD, and
+// the matrix wave keeps no environment registers: both roles fit 256 registers, two waves per SIMD.  The means travel
+// through the tile's obs stage (the matrix wave has its observations in registers by then), the values through a
+// buffer private to the matrix wave.  Every wave passes the same 2 T + 1 workgroup barriers.  FAST as in k_runner_rollout;
+// the heads are the same instruction sequences on the same operands as there, so the two kernels agree bit for bit.
+template <int INTEG, int RMODE, bool PARAMS, bool FAST>
+__global__ __launch_bounds__(2 * kBlock, 1) void k_runner_split(StepArgs A, RunnerArgs R)
+{
+    constexpr int kHeadBytes = FAST ? kAcFastLdsBytes : (int)(ac_lds_floats() * sizeof(float));     // weights + 4 obs stages
+    __shared__ __attribute__((aligned(16))) char lds_raw[kHeadBytes + 4 * kTile * 4];
+    AcLds L{};
+    float *sStage;
+    if (FAST) {
+        for (int i = threadIdx.x; i < kAcFastBlobBytes / 16; i += 2 * kBlock) reinterpret_cast<uint4 *>(lds_raw)[i] = R.blob[i];
+        sStage = reinterpret_cast<float *>(lds_raw + kAcFastBlobBytes);
+    } else {
+        float *sW2p = reinterpret_cast<float *>(lds_raw);
+        float *sW2v = sW2p + kHid * kLdW;
+        float *sW3p = sW2v + kHid * kLdW;
+        float *sW3v = sW3p + 4 * kLdW;
+        float *sW1 = sW3v + kLdW;
+        float *sB1 = sW1 + kHid * kLdW1;
+        float *sB2p = sB1 + kHid;
+        float *sB2v = sB2p + kHid;
+        float *sB3 = sB2v + kHid;
+        sStage = sB3 + 16;
+        for (int i = threadIdx.x; i < kHid * kHid; i += 2 * kBlock) {
+            sW2p[(i >> 7) * kLdW + (i & 127)] = R.net.wt2[i];
+            sW2v[(i >> 7) * kLdW + (i & 127)] = R.net.wtv2[i];
+        }
+        for (int i = threadIdx.x; i < 4 * kHid; i += 2 * kBlock) sW3p[(i >> 7) * kLdW + (i & 127)] = R.net.wt3[i];
+        for (int i = threadIdx.x; i < kHid; i += 2 * kBlock) sW3v[i] = R.net.wtv3[i];
+        for (int i = threadIdx.x; i < kHid * 12; i += 2 * kBlock) sW1[(i / 12) * kLdW1 + (i % 12)] = R.net.wt1[i];
+        for (int i = threadIdx.x; i < kHid; i += 2 * kBlock) { sB1[i] = R.net.b1[i]; sB2p[i] = R.net.b2[i]; sB2v[i] = R.net.bv2[i]; }
+        if (threadIdx.x < 16) sB3[threadIdx.x] = threadIdx.x < 4 ? R.net.b3[threadIdx.x] : (threadIdx.x == 4 ? R.net.bv3[0] : 0.0f);
+        L = AcLds{sW1, sB1, sW2p, sB2p, sW2v, sB2v, sW3p, sW3v, sB3};
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & (kTile - 1);
+    const int w = (threadIdx.x >> 6) & 3;
+    const bool matrix_role = threadIdx.x < kBlock;
+    const int64_t tile = (int64_t)blockIdx.x * (kBlock / kTile) + w;
+    const int64_t env = tile * kTile + lane;
+    const bool active = env < A.n;             // MFMA needs the whole wave: idle lanes carry a nominal env, store nothing
+    float *stage = sStage + w * (12 * 64);
+    float *sval = reinterpret_cast<float *>(lds_raw + kHeadBytes) + w * kTile;
+    QS_ASSERT((char *)(stage + 12 * 64) <= lds_raw + kHeadBytes);
+    if (matrix_role) {
+#ifdef QS_EXP_M_PRIO
+        __builtin_amdgcn_s_setprio(3);
+#endif
+        const int c = lane & 15, g = lane >> 4;
+        // layer-1 result = the B operands of both 128 x 128 branches, 128 registers either way
+        u32x4 bh[FAST ? 4 : 1][4], bl[FAST ? 4 : 1][4];
+        f32x4 h1[FAST ? 1 : 8][4];
+        f32x4 a3[4];
+        QS_PHASE_DECL;
+#pragma clang loop unroll(disable)
+        for (int64_t t = 0; t <= A.T; ++t) {
+            __syncthreads();                                                  // #a: this step's observations are in LDS
+            QS_PHASE(0);
+            if constexpr (FAST) ac_fast_layer1(lds_raw, stage, lane, bh, bl);
+            else ac_exact_layer1(L, stage, lane, h1);
+            QS_PHASE(1);
+            if (t < A.T) {
+                if constexpr (FAST) ac_fast_branch<0>(lds_raw, bh, bl, lane, a3);
+                else ac_exact_branch<0>(L, h1, lane, a3);
+                if (g == 0) {
+#pragma unroll
+                    for (int et = 0; et < 4; ++et) *reinterpret_cast<f32x4 *>(stage + (16 * et + c) * 8) = a3[et];
+                }
+                QS_PHASE(2);
+                __syncthreads();                                              // #b: the means are in LDS
+                QS_PHASE(3);
+            }
+            if constexpr (FAST) ac_fast_branch<1>(lds_raw, bh, bl, lane, a3);
+            else ac_exact_branch<1>(L, h1, lane, a3);
+            QS_PHASE(4);
+            if (g == 1) {
+#pragma unroll
+                for (int et = 0; et < 4; ++et) sval[16 * et + c] = a3[et][0];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const float v = sval[lane];
+            __builtin_amdgcn_wave_barrier();
+            if (active) {
+                if (t < A.T) R.values[t * A.n + env] = v;
+                else R.last_values[env] = v;                                  // model.value(obs) after the last step (ppo2.py:506)
+            }
+            QS_PHASE(5);
+        }
+        QS_PHASE_FLUSH(0);
+    } else {
+        Env e;
+        if (active) load_env(A.st, tile, lane, e);
+        else { nominal_init(e.sc, e.st); for (int i = 0; i < 4; ++i) { e.uc[i] = 0.0f; e.ut[i] = 0.0f; e.qd[i] = i == 0; } e.ls = 0.0f; e.t = 0.0f; }
+        Par P = A.par_nom;
+        if (PARAMS && active) P = load_par(A.par, tile, lane);
+        const uint64_t k0 = active ? step_counter_begin(A, tile) : 0;
+        bool done_prev = (active && R.dones_in) ? R.dones_in[env] != 0 : false;
+        float obs[12];
+        rel_obs(e.sc, e.st, obs);
+#pragma unroll
+        for (int k = 0; k < 12; ++k) stage[k * 64 + lane] = obs[k];
+        QS_PHASE_DECL;
+#pragma clang loop unroll(disable)
+        for (int64_t t = 0; t < A.T; ++t) {
+            const int64_t o = t * A.n + env;
+            QS_ASSERT(!active || (o >= 0 && o < A.T * A.n));
+            const int64_t ow = R.env_major ? env * A.T + t : o;
+            if (active) { if (R.env_major) store_obs_cached(A.obs, ow, obs); else store_obs(A.obs, ow, obs); }
+            QS_PHASE(0);
+            __syncthreads();                                                  // #a
+            QS_PHASE(1);
+            float eps[4];
+            if (R.noise) {
+                const float4 nv = active ? reinterpret_cast<const float4 *>(R.noise)[o] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+                eps[0] = nv.x; eps[1] = nv.y; eps[2] = nv.z; eps[3] = nv.w;
+            } else {
+#ifdef QS_EXP_E_IDLE
+                eps[0] = eps[1] = eps[2] = eps[3] = 0.1f;
+#else
+                random_normal4(A.rc.seed, A.gid0 + (uint64_t)(active ? env : 0), k0 + (uint64_t)t, eps);
+#endif
+            }
+            QS_PHASE(2);
+            __syncthreads();                                                  // #b
+            QS_PHASE(3);
+            const f32x4 mean = *reinterpret_cast<const f32x4 *>(stage + lane * 8);
+            float u[4], a[4];
+            float nl = R.nl_const;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                u[i] = fmaf(R.std[i], eps[i], mean[i]);                       // distributions.py:429
+                const float d = (u[i] - mean[i]) * R.inv_std[i];              // :407
+                nl = fmaf(0.5f * d, d, nl);
+            }
+            if (R.squash) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float sech2;
+                    a[i] = q_tanh(u[i], sech2);                               // policies.py:238
+                    nl += q_ln(sech2 + 1e-6f);                                // distributions.py:414
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = fminf(fmaxf(u[i], -1.0f), 1.0f);   // ppo2.py:483
+            }
+            if (active) {
+                reinterpret_cast<float4 *>(R.actions)[ow] = make_float4(u[0], u[1], u[2], u[3]);
+                R.neglogp[o] = nl;
+                A.done[o] = done_prev ? 1 : 0;                                // mb_dones: flags before the step (ppo2.py:479)
+            }
+            QS_PHASE(4);
+            float reward;
+            unsigned flags;
+            bool done;
+#ifdef QS_EXP_E_IDLE
+            reward = a[0]; flags = 0; done = false;
+#else
+            step_and_maybe_reset<INTEG, PARAMS, RMODE>(e, P, a, A, active ? env : 0, k0 + (uint64_t)t, obs, reward, flags, done, false);
+#endif
+            done_prev = done;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) stage[k * 64 + lane] = obs[k];
+            if (active) {
+                A.reward[o] = reward;
+                if (A.flags) A.flags[o] = (uint8_t)flags;
+            }
+            QS_PHASE(5);
+        }
+        QS_PHASE_FLUSH(1);
+        __syncthreads();                                                      // #a of the value-only pass
+        if (active) {
+            R.last_dones[env] = done_prev ? 1 : 0;
+            if (R.last_obs) store_obs(R.last_obs, env, obs);
+            store_env(A.st, tile, lane, e);
+            if (PARAMS && RMODE == 2) store_par(A.par, tile, lane, P);
+            step_counter_end(A, tile, lane, k0);
+        }
     }
 }
 
@@ -2782,8 +2987,26 @@ static int runner_launch(QsEnv *e, const char *who, int64_t T, const float logst
         else if (params) QS_RUNNER_GO(I, 0, true, FAST);          \
         else QS_RUNNER_GO(I, 0, false, FAST);                     \
     } while (0)
-    if (blob) { if (fr) QS_RUNNER_INTEG(0, true); else QS_RUNNER_INTEG(1, true); }
+    // the role-split kernel (matrix waves + env waves); QUADSIM_RUNNER_SERIAL=1 keeps the one-wave-per-tile kernel for A/B
+    // runs (same results bit for bit: the same instruction sequences on the same operands)
+    static const bool serial_fast = [] { const char *v = getenv("QUADSIM_RUNNER_SERIAL"); return v && v[0] == '1'; }();
+#define QS_RUNNER_SPLIT_GO(I, RM, PA, FAST) hipLaunchKernelGGL((k_runner_split<I, RM, PA, FAST>), dim3(grid), dim3(2 * kBlock), 0, e->stream, A, R)
+#define QS_RUNNER_SPLIT(I, FAST)                                        \
+    do {                                                                \
+        if (rm == 2) QS_RUNNER_SPLIT_GO(I, 2, true, FAST);              \
+        else if (rm == 1 && params) QS_RUNNER_SPLIT_GO(I, 1, true, FAST);  \
+        else if (rm == 1) QS_RUNNER_SPLIT_GO(I, 1, false, FAST);        \
+        else if (params) QS_RUNNER_SPLIT_GO(I, 0, true, FAST);          \
+        else QS_RUNNER_SPLIT_GO(I, 0, false, FAST);                     \
+    } while (0)
+    if (!serial_fast) {
+        if (blob) { if (fr) QS_RUNNER_SPLIT(0, true); else QS_RUNNER_SPLIT(1, true); }
+        else { if (fr) QS_RUNNER_SPLIT(0, false); else QS_RUNNER_SPLIT(1, false); }
+    }
+    else if (blob) { if (fr) QS_RUNNER_INTEG(0, true); else QS_RUNNER_INTEG(1, true); }
     else { if (fr) QS_RUNNER_INTEG(0, false); else QS_RUNNER_INTEG(1, false); }
+#undef QS_RUNNER_SPLIT
+#undef QS_RUNNER_SPLIT_GO
 #undef QS_RUNNER_INTEG
 #undef QS_RUNNER_GO
     HIP_TRY(hipGetLastError());
