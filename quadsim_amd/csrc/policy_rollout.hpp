@@ -288,7 +288,7 @@ __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 w) { return __builtin_bit_cast
 // order, pinned by scheduling barriers: MFMA m of tile s + 1 (order k-step | term | env tile, so that consecutive MFMAs use
 // different accumulators), then ONE instruction-sized piece of the split of tile s (pair m / 6, piece m % 6); the A fragments
 // of k-step p + 1 are requested while k-step p multiplies.  Runner, 65 536 envs: 17.1 -> 15.2 us per step.
-struct L2Tile { const bf16x8 *hi, *lo; const float *bias; };     // fragments [k-step][lane] of the tile, bias of its 16 rows
+struct L2Tile { const bf16x8 *hi, *lo; const float *bias; };     // fragments [k-step][lane] of the tile; the lane's 4 bias rows
 
 // NET / E0: the pass covers env tiles E0 .. E0 + NET - 1 of the wave's four (a 2-tile pass halves the working set of
 // accumulators and output-layer operands; the role-split runner's matrix waves run two such passes per branch).
@@ -298,7 +298,7 @@ __device__ __forceinline__ void mlp_layer2_split(const u32x4 (&bh)[4][4], const 
 {
     auto h2_tile = [&](int s2, f32x4 (&h2)[NET]) {
         const L2Tile t = tile_of(s2);
-        const f32x4 bias = *reinterpret_cast<const f32x4 *>(t.bias + 4 * g);
+        const f32x4 bias = *reinterpret_cast<const f32x4 *>(t.bias);
 #pragma unroll
         for (int et = 0; et < NET; ++et) h2[et] = bias;
 #pragma unroll
@@ -328,7 +328,7 @@ __device__ __forceinline__ void mlp_layer2_split(const u32x4 (&bh)[4][4], const 
     auto woven_stage = [&](int s2n, f32x4 (&hn)[NET], const f32x4 (&hc)[NET], int half) {
         const L2Tile t = tile_of(s2n);
         const bf16x8 *A2hi = t.hi + lane, *A2lo = t.lo + lane;
-        const f32x4 bias = *reinterpret_cast<const f32x4 *>(t.bias + 4 * g);
+        const f32x4 bias = *reinterpret_cast<const f32x4 *>(t.bias);
         bf16x8 ah[2], al[2];
         ah[0] = A2hi[0]; al[0] = A2lo[0];
         float v0[2 * NET], v1[2 * NET], h0[2 * NET], h1[2 * NET];
@@ -435,7 +435,7 @@ __device__ __forceinline__ void mlp_actor_fast(const float obs[12], float act[4]
         for (int et = 0; et < 4; ++et) a3[et] = bias3;
     }
     mlp_layer2_split<8, 4, 0>(bh, bl, lane, g,
-        [&](int nt) { return L2Tile{A2hi + nt * 4 * 64, A2lo + nt * 4 * 64, sB2 + 16 * nt}; },
+        [&](int nt) { return L2Tile{A2hi + nt * 4 * 64, A2lo + nt * 4 * 64, sB2 + 16 * nt + 4 * g}; },
         [&](int q, const u32x4 (&ch)[4], const u32x4 (&cl)[4]) {
             const bf16x8 wh = A3hi[q * 64 + lane], wl = A3lo[q * 64 + lane];
 #pragma unroll
@@ -522,7 +522,7 @@ __device__ __forceinline__ void mlp_actor_critic_fast(const float obs[12], float
             const int br = s2 >> 3, nt = s2 & 7;
             return L2Tile{reinterpret_cast<const bf16x8 *>(blob + kAcFastA2 + br * 65536) + nt * 4 * 64,
                           reinterpret_cast<const bf16x8 *>(blob + kAcFastA2 + br * 65536 + 32768) + nt * 4 * 64,
-                          (br ? sB2v : sB2p) + 16 * nt};
+                          (br ? sB2v : sB2p) + 16 * nt + 4 * g};
         },
         [&](int pair, const u32x4 (&ch)[4], const u32x4 (&cl)[4]) {
             // output-layer A fragments: rows 0..3 (policy) / row 4 (value) hold weights, every other row of the 16-row tile
@@ -560,8 +560,8 @@ __device__ __forceinline__ void mlp_actor_critic_fast(const float obs[12], float
 // Role-split runner (k_runner_split): the heads cut into the pieces a MATRIX wave runs while an ENV wave of the same tile
 // steps the environments.  ac_fast_layer1: shared layer for the wave's 64 envs (observations read from the tile's LDS
 // stage, [k][env]), result = the B operands of BOTH 128 x 128 branches, kept in registers.  ac_fast_branch<BR>: one branch
-// (0 policy -> rows 0..3 of a3, 1 value -> row 4) in two passes of two env tiles (256 registers per wave at two waves per
-// SIMD: a four-tile pass does not fit next to the 128 operand registers).
+// (0 policy -> rows 0..3 of a3, 1 value -> row 4) over QS_SPLIT_NET env tiles per pass (256 registers per wave at two waves
+// per SIMD: next to the 128 operand registers the four-tile pass leaves a dozen loop-invariant values in scratch).
 __device__ __forceinline__ void ac_fast_layer1(const char *blob, const float *stage, int lane, u32x4 (&bh)[4][4], u32x4 (&bl)[4][4])
 {
     const float *sW1 = reinterpret_cast<const float *>(blob + kAcFastW1);
@@ -595,27 +595,40 @@ __device__ __forceinline__ void ac_fast_layer1(const char *blob, const float *st
 }
 
 #ifndef QS_SPLIT_NET
-#define QS_SPLIT_NET 2      // env tiles per layer-2 pass of a matrix wave
+#define QS_SPLIT_NET 4      // env tiles per layer-2 pass of a matrix wave: 4 = one pass; 2 = two passes with half the working set,
+                            // but only two accumulators in flight -- a dependent v_mfma_f32_16x16x32_bf16 two instructions behind
+                            // its producer waits for it (measured 22 cycles per MFMA against 18.5 with four)
 #endif
+// An LDS byte offset the optimiser cannot see through: everything addressed as `blob + opaque + constant` then shares ONE
+// address register with the constants in the instructions' offset fields, instead of one materialised address per constant
+// (the matrix wave has 256 registers for 128 operand registers plus its working set; 25 such addresses went to scratch).
+__device__ __forceinline__ int lds_opaque(int off)
+{
+    asm volatile("" : "+v"(off));
+    return off;
+}
+
+// zeros: byte offset (from blob) of 2 KiB of zeros -- what the dead rows of the output-layer A tiles read
 template <int BR, int E0>
-__device__ __forceinline__ void ac_fast_branch_pass(const char *blob, const u32x4 (&bh)[4][4], const u32x4 (&bl)[4][4], int lane,
+__device__ __forceinline__ void ac_fast_branch_pass(const char *blob, int zeros, const u32x4 (&bh)[4][4], const u32x4 (&bl)[4][4], int lane,
                                                     f32x4 (&a3)[4])
 {
-    const float *sB1 = reinterpret_cast<const float *>(blob + kAcFastB);
-    const float *sB2 = sB1 + (1 + BR) * kHid, *sB3 = sB1 + 3 * kHid;
     const int c = lane & 15, g = lane >> 4;
+    const char *bias_base = blob + lds_opaque(kAcFastB + 16 * g);                       // + 512 (1 + BR) + 64 nt
+    // output-layer A fragments: rows 0..3 (policy, [q][row][g]) / row 4 (value, [q][g]) hold weights, every other row of the
+    // 16-row tile reads zeros: ONE address select per pass, the k-step q and the hi / lo half in the offset field
+    const bool row_live = BR == 0 ? c < 4 : c == 4;
+    const int a3_off = BR == 0 ? kAcFastA3p + ((c & 3) * 4 + g) * 16 : kAcFastA3v + g * 16;
+    const char *a3_base = blob + lds_opaque(row_live ? a3_off : zeros);
     mlp_layer2_split<8, QS_SPLIT_NET, E0>(bh, bl, lane, g,
         [&](int nt) {
             return L2Tile{reinterpret_cast<const bf16x8 *>(blob + kAcFastA2 + BR * 65536) + nt * 4 * 64,
-                          reinterpret_cast<const bf16x8 *>(blob + kAcFastA2 + BR * 65536 + 32768) + nt * 4 * 64, sB2 + 16 * nt};
+                          reinterpret_cast<const bf16x8 *>(blob + kAcFastA2 + BR * 65536 + 32768) + nt * 4 * 64,
+                          reinterpret_cast<const float *>(bias_base + 512 * (1 + BR) + 64 * nt)};
         },
         [&](int q, const u32x4 (&ch)[QS_SPLIT_NET], const u32x4 (&cl)[QS_SPLIT_NET]) {
-            const bf16x8 *ph = BR == 0 ? reinterpret_cast<const bf16x8 *>(blob + kAcFastA3p) + (q * 4 + (c & 3)) * 4 + g
-                                       : reinterpret_cast<const bf16x8 *>(blob + kAcFastA3v) + q * 4 + g;
-            const bf16x8 *pl = BR == 0 ? ph + 1024 / 16 : ph + 256 / 16;
-            const bool row_live = BR == 0 ? c < 4 : c == 4;
-            const bf16x8 *pz = reinterpret_cast<const bf16x8 *>(sB3 + 8);
-            const bf16x8 wh = *(row_live ? ph : pz), wl = *(row_live ? pl : pz);
+            const bf16x8 wh = *reinterpret_cast<const bf16x8 *>(a3_base + q * (BR == 0 ? 256 : 64));
+            const bf16x8 wl = *reinterpret_cast<const bf16x8 *>(a3_base + q * (BR == 0 ? 256 : 64) + (BR == 0 ? 1024 : 256));
 #pragma unroll
             for (int et = 0; et < QS_SPLIT_NET; ++et) {
                 a3[E0 + et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, as_bf16x8(ch[et]), a3[E0 + et], 0, 0, 0);
@@ -626,14 +639,15 @@ __device__ __forceinline__ void ac_fast_branch_pass(const char *blob, const u32x
 }
 
 template <int BR>
-__device__ __forceinline__ void ac_fast_branch(const char *blob, const u32x4 (&bh)[4][4], const u32x4 (&bl)[4][4], int lane, f32x4 (&a3)[4])
+__device__ __forceinline__ void ac_fast_branch(const char *blob, int zeros, const u32x4 (&bh)[4][4], const u32x4 (&bl)[4][4], int lane,
+                                               f32x4 (&a3)[4])
 {
     const float *sB3 = reinterpret_cast<const float *>(blob + kAcFastB) + 3 * kHid;
     const f32x4 bias3 = *reinterpret_cast<const f32x4 *>(sB3 + 4 * (lane >> 4));
 #pragma unroll
     for (int et = 0; et < 4; ++et) a3[et] = bias3;
-    ac_fast_branch_pass<BR, 0>(blob, bh, bl, lane, a3);
-    if (QS_SPLIT_NET == 2) ac_fast_branch_pass<BR, QS_SPLIT_NET == 2 ? 2 : 0>(blob, bh, bl, lane, a3);
+    ac_fast_branch_pass<BR, 0>(blob, zeros, bh, bl, lane, a3);
+    if (QS_SPLIT_NET == 2) ac_fast_branch_pass<BR, QS_SPLIT_NET == 2 ? 2 : 0>(blob, zeros, bh, bl, lane, a3);
 }
 
 // The exact-float32 heads in the same two pieces: identical MFMA sequences per accumulator as mlp_actor_critic -- the one

@@ -616,6 +616,32 @@ __device__ __forceinline__ void env_step(Env &e, const float a[4], const Par &P,
 
 // DockingEnv.reset (docking_env.py:233-244) + Drone.reset (quadrotor.py:65-78):
 // new initial states, stored controls, t and last_shaping zeroed, q_des untouched.
+// env_step in two halves for a caller that has the action late (role-split Runner kernel: the target's half runs while the
+// policy is still being evaluated).  The target's half does not see the action: its command from the state BEFORE stepping,
+// then its step; the chaser's half is the rest.  The same operations on the same operands as env_step, so the same bits.
+template <int INTEG>
+__device__ __forceinline__ bool env_step_target(Env &e, const Par &P, const EnvConst &C)
+{
+    float u_t[4];
+    const float pdes[3] = {10.0f, -50.0f, 5.0f};              // :60
+    const float vdes[3] = {C.vdes_x, 0.0f, 0.0f};
+    const float dv[3] = {0.0f, 0.0f, 0.0f};                   // state_last aliases state_now (moving_docking_env.py:117)
+    target_control(C.kind, pdes, vdes, e.qd, 0.0f, e.st, dv, P.m, u_t);
+    return drone_step<INTEG>(e.st, e.ut, u_t, P, C.dt);       // :120
+}
+
+template <int INTEG>
+__device__ __forceinline__ void env_step_chaser(Env &e, const float a[4], const Par &P, const EnvConst &C, bool lim_t, float obs[12],
+                                                float &reward, unsigned &flags)
+{
+    e.t += 1.0f;                                              // :108
+    float u_c[4];
+    chaser_command(a, P.m, u_c);                              // :115
+    bool lim_c = drone_step<INTEG>(e.sc, e.uc, u_c, P, C.dt); // :121
+    rel_obs(e.sc, e.st, obs);                                 // :124-127
+    score_step(obs, a, e.sc[2], e.t, e.ls, C, lim_c, lim_t, reward, flags);
+}
+
 template <bool TARGET_LEVEL = false>
 __device__ __forceinline__ void env_reset(Env &e, const float ic[13], const float it[13], float obs[12])
 {

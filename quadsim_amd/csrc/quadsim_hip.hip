@@ -247,6 +247,10 @@ __device__ __forceinline__ bool chain_tile_misplaced(const StepArgs &A, int64_t 
     return false;
 }
 
+template <bool PARAMS, int RMODE>
+__device__ __forceinline__ void maybe_reset(Env &e, Par &P, const StepArgs &A, int64_t env, uint64_t k, float obs[12], unsigned flags,
+                                            bool &done, bool write_term);
+
 // RMODE (compile time) = the handle's `randomise`: 0 nominal reset, 1 rocRAND init state, 2 + params.
 template <int INTEG, bool PARAMS, int RMODE>
 __device__ __forceinline__ void step_and_maybe_reset(Env &e, Par &P, const float a[4], const StepArgs &A, int64_t env,
@@ -254,6 +258,13 @@ __device__ __forceinline__ void step_and_maybe_reset(Env &e, Par &P, const float
                                                      bool &done, bool write_term)
 {
     env_step<INTEG>(e, a, P, A.C, obs, reward, flags);
+    maybe_reset<PARAMS, RMODE>(e, P, A, env, k, obs, flags, done, write_term);
+}
+
+template <bool PARAMS, int RMODE>
+__device__ __forceinline__ void maybe_reset(Env &e, Par &P, const StepArgs &A, int64_t env, uint64_t k, float obs[12], unsigned flags,
+                                            bool &done, bool write_term)
+{
     done = (flags & (FLAG_OVERLIMIT | FLAG_OVERTIME)) != 0;
     if (done && A.auto_reset) {
         if (write_term && A.term_obs) store_obs(A.term_obs, env - A.io_env0, obs);
@@ -815,8 +826,8 @@ __global__ __launch_bounds__(kBlock, 1) void k_runner_rollout(StepArgs A, Runner
 // Role-split variant of the Runner kernel: one workgroup = four tiles = EIGHT waves.  Waves 0..3 ("matrix" role,
 // one per SIMD) only evaluate the networks, waves 4..7 ("env" role, wave 4 + i next to wave i) own the environment state of
 // the same four tiles: sampling, neglogp, env.step, every mb_* store except the values.  Per step and tile
-//   env wave:     obs -> LDS | draw N(0,1)            -> #b -> sample, neglogp, stores, env.step, new obs -> LDS  -> #a
-//   matrix wave:  -> #a -> layer 1, policy branch, means -> LDS -> #b -> value branch, store value
+//   env wave:     obs -> LDS | draw N(0,1), target's half of env.step -> #b -> sample, neglogp, stores, chaser's half, new obs -> LDS -> #a
+//   matrix wave:  -> #a -> layer 1, policy branch, means -> LDS       -> #b -> value branch, store value
 // so the value branch (almost half of a step's MFMAs) and the env step (VALU) run at the same time on the same SIMD, and
 // the matrix wave keeps no environment registers: both roles fit 256 registers, two waves per SIMD.  The means travel
 // through the tile's obs stage (the matrix wave has its observations in registers by then), the values through a
@@ -826,11 +837,13 @@ template <int INTEG, int RMODE, bool PARAMS, bool FAST>
 __global__ __launch_bounds__(2 * kBlock, 1) void k_runner_split(StepArgs A, RunnerArgs R)
 {
     constexpr int kHeadBytes = FAST ? kAcFastLdsBytes : (int)(ac_lds_floats() * sizeof(float));     // weights + 4 obs stages
-    __shared__ __attribute__((aligned(16))) char lds_raw[kHeadBytes + 4 * kTile * 4];
+    constexpr int kZeros = kHeadBytes + 4 * kTile * 4;                                              // FAST: 2 KiB of zeros
+    __shared__ __attribute__((aligned(16))) char lds_raw[kZeros + (FAST ? 2048 : 0)];
     AcLds L{};
     float *sStage;
     if (FAST) {
         for (int i = threadIdx.x; i < kAcFastBlobBytes / 16; i += 2 * kBlock) reinterpret_cast<uint4 *>(lds_raw)[i] = R.blob[i];
+        if (threadIdx.x < 128) reinterpret_cast<uint4 *>(lds_raw + kZeros)[threadIdx.x] = make_uint4(0, 0, 0, 0);
         sStage = reinterpret_cast<float *>(lds_raw + kAcFastBlobBytes);
     } else {
         float *sW2p = reinterpret_cast<float *>(lds_raw);
@@ -865,9 +878,6 @@ __global__ __launch_bounds__(2 * kBlock, 1) void k_runner_split(StepArgs A, Runn
     float *sval = reinterpret_cast<float *>(lds_raw + kHeadBytes) + w * kTile;
     QS_ASSERT((char *)(stage + 12 * 64) <= lds_raw + kHeadBytes);
     if (matrix_role) {
-#ifdef QS_EXP_M_PRIO
-        __builtin_amdgcn_s_setprio(3);
-#endif
         const int c = lane & 15, g = lane >> 4;
         // layer-1 result = the B operands of both 128 x 128 branches, 128 registers either way
         u32x4 bh[FAST ? 4 : 1][4], bl[FAST ? 4 : 1][4];
@@ -882,7 +892,7 @@ __global__ __launch_bounds__(2 * kBlock, 1) void k_runner_split(StepArgs A, Runn
             else ac_exact_layer1(L, stage, lane, h1);
             QS_PHASE(1);
             if (t < A.T) {
-                if constexpr (FAST) ac_fast_branch<0>(lds_raw, bh, bl, lane, a3);
+                if constexpr (FAST) ac_fast_branch<0>(lds_raw, kZeros, bh, bl, lane, a3);
                 else ac_exact_branch<0>(L, h1, lane, a3);
                 if (g == 0) {
 #pragma unroll
@@ -892,7 +902,7 @@ __global__ __launch_bounds__(2 * kBlock, 1) void k_runner_split(StepArgs A, Runn
                 __syncthreads();                                              // #b: the means are in LDS
                 QS_PHASE(3);
             }
-            if constexpr (FAST) ac_fast_branch<1>(lds_raw, bh, bl, lane, a3);
+            if constexpr (FAST) ac_fast_branch<1>(lds_raw, kZeros, bh, bl, lane, a3);
             else ac_exact_branch<1>(L, h1, lane, a3);
             QS_PHASE(4);
             if (g == 1) {
@@ -937,12 +947,10 @@ __global__ __launch_bounds__(2 * kBlock, 1) void k_runner_split(StepArgs A, Runn
                 const float4 nv = active ? reinterpret_cast<const float4 *>(R.noise)[o] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
                 eps[0] = nv.x; eps[1] = nv.y; eps[2] = nv.z; eps[3] = nv.w;
             } else {
-#ifdef QS_EXP_E_IDLE
-                eps[0] = eps[1] = eps[2] = eps[3] = 0.1f;
-#else
                 random_normal4(A.rc.seed, A.gid0 + (uint64_t)(active ? env : 0), k0 + (uint64_t)t, eps);
-#endif
             }
+            // the target's half of env.step does not need the action: it runs here, next to the policy branch
+            const bool lim_t = env_step_target<INTEG>(e, P, A.C);
             QS_PHASE(2);
             __syncthreads();                                                  // #b
             QS_PHASE(3);
@@ -975,11 +983,8 @@ __global__ __launch_bounds__(2 * kBlock, 1) void k_runner_split(StepArgs A, Runn
             float reward;
             unsigned flags;
             bool done;
-#ifdef QS_EXP_E_IDLE
-            reward = a[0]; flags = 0; done = false;
-#else
-            step_and_maybe_reset<INTEG, PARAMS, RMODE>(e, P, a, A, active ? env : 0, k0 + (uint64_t)t, obs, reward, flags, done, false);
-#endif
+            env_step_chaser<INTEG>(e, a, P, A.C, lim_t, obs, reward, flags);
+            maybe_reset<PARAMS, RMODE>(e, P, A, active ? env : 0, k0 + (uint64_t)t, obs, flags, done, false);
             done_prev = done;
 #pragma unroll
             for (int k = 0; k < 12; ++k) stage[k * 64 + lane] = obs[k];
@@ -2944,6 +2949,14 @@ int qs_policy_rollout_fast(QsEnv *e, int64_t T, const void *packed_weights, floa
 
 int qs_policy_rollout_fast_blob_bytes(void) { return kFastBlobBytes; }
 
+// 1: the one-wave-per-tile Runner kernels, 0: the role-split ones (default; QUADSIM_RUNNER_SERIAL=1 or the diagnostic entry
+// below select the former for A/B runs and for the bit-identity test)
+static std::atomic<int> &runner_serial_flag()
+{
+    static std::atomic<int> flag{[] { const char *v = getenv("QUADSIM_RUNNER_SERIAL"); return (v && v[0] == '1') ? 1 : 0; }()};
+    return flag;
+}
+
 static int runner_launch(QsEnv *e, const char *who, int64_t T, const float logstd[4], int squash, const AcArgs *net,
                          const void *blob, const float *noise, const uint8_t *dones_in, float *mb_obs, float *mb_actions,
                          float *mb_values, float *mb_neglogp, uint8_t *mb_dones, float *mb_rewards, uint8_t *mb_flags,
@@ -2989,7 +3002,7 @@ static int runner_launch(QsEnv *e, const char *who, int64_t T, const float logst
     } while (0)
     // the role-split kernel (matrix waves + env waves); QUADSIM_RUNNER_SERIAL=1 keeps the one-wave-per-tile kernel for A/B
     // runs (same results bit for bit: the same instruction sequences on the same operands)
-    static const bool serial_fast = [] { const char *v = getenv("QUADSIM_RUNNER_SERIAL"); return v && v[0] == '1'; }();
+    const bool serial_fast = runner_serial_flag().load(std::memory_order_relaxed) != 0;
 #define QS_RUNNER_SPLIT_GO(I, RM, PA, FAST) hipLaunchKernelGGL((k_runner_split<I, RM, PA, FAST>), dim3(grid), dim3(2 * kBlock), 0, e->stream, A, R)
 #define QS_RUNNER_SPLIT(I, FAST)                                        \
     do {                                                                \
@@ -3040,6 +3053,10 @@ int qs_runner_rollout_fast(QsEnv *e, int64_t T, const void *packed_weights, cons
 }
 
 int qs_runner_rollout_fast_blob_bytes(void) { return kAcFastBlobBytes; }
+
+// Diagnostic (not in quadsim.h; tests and A/B tools only): Runner kernel flavour for every later qs_runner_rollout* call of
+// the process -- 1 one wave per tile, 0 role-split (matrix waves + env waves).  Returns the previous setting.
+int qs_debug_set_runner_serial(int on) { return runner_serial_flag().exchange(on ? 1 : 0); }
 
 int qs_set_queue_mode(QsEnv *e, int32_t mode)
 {

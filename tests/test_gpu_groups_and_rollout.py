@@ -439,3 +439,48 @@ def test_private_queue_placement_guard_fails_loudly(qa, torch):
     env.step(acts[1])                                      # the handle recovers: owners are re-learnt after the HIP-side calls above
     assert env.step_counter == k_before + 1
     env.close()
+
+
+def test_runner_role_split_kernel_is_bit_identical_to_one_wave_per_tile(qa):
+    """k_runner_split (matrix waves + env waves, the default) against k_runner_rollout (one wave per tile) on the same envs:
+    every output array and the final env state bit for bit -- exact-f32 and split-bf16 heads, plain and squashed policy,
+    in-kernel normals and caller noise, rocRAND resets with and without per-env parameters, ragged env counts, carried-over
+    done flags, both roll-out layouts"""
+    import torch
+    from test_gpu_parity import _ac_policy
+    lib = qa._lib.load()
+    lib.qs_debug_set_runner_serial.argtypes = [C.c_int]
+    cases = [dict(n=3000, T=20, prec="f32", squash=False, rand=1, noise=False, env_major=False),
+             dict(n=3000, T=20, prec="bf16x3", squash=False, rand=1, noise=True, env_major=False),
+             dict(n=64 * 7 + 5, T=33, prec="f32", squash=True, rand=2, noise=False, env_major=True),
+             dict(n=64 * 7 + 5, T=33, prec="bf16x3", squash=True, rand=2, noise=False, env_major=True),
+             dict(n=1, T=9, prec="f32", squash=False, rand=0, noise=True, env_major=False),
+             dict(n=8192, T=12, prec="bf16x3", squash=False, rand=0, noise=False, env_major=False)]
+    try:
+        for cs in cases:
+            pol, _ = _ac_policy(qa, cs["squash"])
+            res = []
+            for serial in (1, 0):
+                lib.qs_debug_set_runner_serial(serial)
+                env = qa.VecDockingEnv("docking-v0", num_envs=cs["n"], randomise=cs["rand"], seed=11, init_range=qa.C3_INIT_RANGE)
+                env.reset()
+                env.set_state(t=np.full(cs["n"], 592.0, np.float32))            # every env times out (and resets) inside the roll-out
+                g = torch.Generator().manual_seed(4)
+                noise = torch.randn((cs["T"], cs["n"], 4), generator=g) if cs["noise"] else None
+                dones_in = (torch.rand(cs["n"], generator=g) < 0.3)
+                out = qa.fused_runner_rollout(env, pol, cs["T"], noise=noise, dones_in=dones_in, want_flags=True,
+                                              precision=cs["prec"], env_major=cs["env_major"])
+                rec = {k: v.cpu().numpy() for k, v in out.items()}
+                rec.update({"state_" + k: v for k, v in env.get_state().items()})
+                if cs["rand"] == 2:
+                    m, inertia = env.get_params()
+                    rec["mass"], rec["inertia"] = np.asarray(m), np.asarray(inertia)
+                rec["counter"] = np.int64(env.step_counter)
+                res.append(rec)
+                env.close()
+            a, b = res
+            assert a["dones"].any() and a["counter"] == b["counter"]
+            for k in a:
+                assert np.array_equal(a[k], b[k]), (cs, k, np.abs(a[k].astype(np.float64) - b[k].astype(np.float64)).max())
+    finally:
+        lib.qs_debug_set_runner_serial(0)
