@@ -69,12 +69,14 @@ __device__ __forceinline__ void mlp_actor(const float obs[12], float act[4], con
         float a[3];
 #pragma unroll
         for (int s = 0; s < 3; ++s) a[s] = sW1[(16 * rt + c) * kLdW1 + 4 * s + g];
+        f32x4 acc[4] = {bias, bias, bias, bias};              // k-step outermost: consecutive MFMAs on different accumulators
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int et = 0; et < 4; ++et) acc[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], xb[s][et], acc[et], 0, 0, 0);
 #pragma unroll
         for (int et = 0; et < 4; ++et) {
-            f32x4 acc = bias;
-#pragma unroll
-            for (int s = 0; s < 3; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], xb[s][et], acc, 0, 0, 0);
-            h1[rt][et] = relu4(acc);
+            h1[rt][et] = relu4(acc[et]);
         }
     }
     // ---- layers 2 + 3: for each 16-row tile of H2^T: 32 k-steps over H1^T, bias, ReLU, then straight into the
@@ -99,12 +101,13 @@ __device__ __forceinline__ void mlp_actor(const float obs[12], float act[4], con
                     h2[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i], h1[rt][et][i], h2[et], 0, 0, 0);
         }
         const f32x4 w3 = *reinterpret_cast<const f32x4 *>(sW3 + c * kLdW + 16 * nt + 4 * g);
+        f32x4 r[4];
 #pragma unroll
-        for (int et = 0; et < 4; ++et) {
-            const f32x4 r = relu4(h2[et]);
+        for (int et = 0; et < 4; ++et) r[et] = relu4(h2[et]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a3[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[i], r[i], a3[et], 0, 0, 0);
-        }
+        for (int i = 0; i < 4; ++i)                     // k-step outermost: consecutive MFMAs on different accumulators
+#pragma unroll
+            for (int et = 0; et < 4; ++et) a3[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[i], r[et][i], a3[et], 0, 0, 0);
         // issue order of this tile: every weight read one 16-MFMA group ahead of its use (left alone, hipcc emits
         // read -> wait -> 16 MFMAs and exposes the LDS latency 8 times per tile): 24.9 -> 24.3 us/step.  The same
         // directives change nothing in mlp_actor_critic (43.7 vs 43.8 us/step) and are not applied there.
@@ -174,12 +177,14 @@ __device__ __forceinline__ void mlp_actor_critic(const float obs[12], float out[
         float a[3];
 #pragma unroll
         for (int s = 0; s < 3; ++s) a[s] = L.W1[(16 * rt + c) * kLdW1 + 4 * s + g];
+        f32x4 acc[4] = {bias, bias, bias, bias};              // k-step outermost: consecutive MFMAs on different accumulators
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int et = 0; et < 4; ++et) acc[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], xb[s][et], acc[et], 0, 0, 0);
 #pragma unroll
         for (int et = 0; et < 4; ++et) {
-            f32x4 acc = bias;
-#pragma unroll
-            for (int s = 0; s < 3; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], xb[s][et], acc, 0, 0, 0);
-            h1[rt][et] = relu4(acc);
+            h1[rt][et] = relu4(acc[et]);
         }
     }
     f32x4 a3[4];
@@ -210,12 +215,13 @@ __device__ __forceinline__ void mlp_actor_critic(const float obs[12], float out[
             f32x4 w3 = zero;
             if (br == 0) { if (c < 4) w3 = *reinterpret_cast<const f32x4 *>(L.W3p + c * kLdW + 16 * nt + 4 * g); }
             else { if (c == 4) w3 = *reinterpret_cast<const f32x4 *>(L.W3v + 16 * nt + 4 * g); }
+            f32x4 r[4];
 #pragma unroll
-            for (int et = 0; et < 4; ++et) {
-                const f32x4 r = relu4(h2[et]);
+            for (int et = 0; et < 4; ++et) r[et] = relu4(h2[et]);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) a3[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[i], r[i], a3[et], 0, 0, 0);
-            }
+            for (int i = 0; i < 4; ++i)                     // k-step outermost: consecutive MFMAs on different accumulators
+#pragma unroll
+                for (int et = 0; et < 4; ++et) a3[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[i], r[et][i], a3[et], 0, 0, 0);
         }
     }
     // rows 0..3 sit in lanes g == 0, row 4 in register 0 of lanes g == 1: hand them to the lane that owns the env
@@ -412,16 +418,18 @@ __device__ __forceinline__ void mlp_actor_fast(const float obs[12], float act[4]
     for (int rt = 0; rt < 8; ++rt) {
         const f32x4 bias = *reinterpret_cast<const f32x4 *>(sB1 + 16 * rt + 4 * g);
         const bf16x8 ah = A1hi[rt * 64 + lane], al = A1lo[rt * 64 + lane];
+        f32x4 acc[4] = {bias, bias, bias, bias};              // term outermost: consecutive MFMAs on different accumulators
+#pragma unroll
+        for (int term = 0; term < 3; ++term)
+#pragma unroll
+            for (int et = 0; et < 4; ++et)
+                acc[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(term == 0 ? al : ah, term == 1 ? xl[et] : xh[et], acc[et], 0, 0, 0);
 #pragma unroll
         for (int et = 0; et < 4; ++et) {
-            f32x4 acc = bias;
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, xh[et], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xl[et], acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, xh[et], acc, 0, 0, 0);
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {
                 uint32_t h, l;
-                relu_split_pair(acc[2 * pr], acc[2 * pr + 1], h, l);
+                relu_split_pair(acc[et][2 * pr], acc[et][2 * pr + 1], h, l);
                 bh[rt >> 1][et][2 * (rt & 1) + pr] = h;
                 bl[rt >> 1][et][2 * (rt & 1) + pr] = l;
             }
@@ -439,11 +447,10 @@ __device__ __forceinline__ void mlp_actor_fast(const float obs[12], float act[4]
         [&](int q, const u32x4 (&ch)[4], const u32x4 (&cl)[4]) {
             const bf16x8 wh = A3hi[q * 64 + lane], wl = A3lo[q * 64 + lane];
 #pragma unroll
-            for (int et = 0; et < 4; ++et) {
-                a3[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, as_bf16x8(ch[et]), a3[et], 0, 0, 0);
-                a3[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, as_bf16x8(cl[et]), a3[et], 0, 0, 0);
-                a3[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, as_bf16x8(ch[et]), a3[et], 0, 0, 0);
-            }
+            for (int term = 0; term < 3; ++term)            // term outermost: consecutive MFMAs on different accumulators
+#pragma unroll
+                for (int et = 0; et < 4; ++et)
+                    a3[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(term == 0 ? wl : wh, as_bf16x8(term == 1 ? cl[et] : ch[et]), a3[et], 0, 0, 0);
         });
     if (g == 0) {
 #pragma unroll
@@ -496,15 +503,17 @@ __device__ __forceinline__ void mlp_actor_critic_fast(const float obs[12], float
         float a[3];
 #pragma unroll
         for (int s = 0; s < 3; ++s) a[s] = sW1[(16 * rt + c) * kLdW1 + 4 * s + g];
+        f32x4 acc[4] = {bias, bias, bias, bias};              // k-step outermost: consecutive MFMAs on different accumulators
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int et = 0; et < 4; ++et) acc[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], xb[s][et], acc[et], 0, 0, 0);
 #pragma unroll
         for (int et = 0; et < 4; ++et) {
-            f32x4 acc = bias;
-#pragma unroll
-            for (int s = 0; s < 3; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], xb[s][et], acc, 0, 0, 0);
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {
                 uint32_t h, l;
-                relu_split_pair(acc[2 * pr], acc[2 * pr + 1], h, l);
+                relu_split_pair(acc[et][2 * pr], acc[et][2 * pr + 1], h, l);
                 bh[rt >> 1][et][2 * (rt & 1) + pr] = h;
                 bl[rt >> 1][et][2 * (rt & 1) + pr] = l;
             }
@@ -535,11 +544,10 @@ __device__ __forceinline__ void mlp_actor_critic_fast(const float obs[12], float
             const bf16x8 *pz = reinterpret_cast<const bf16x8 *>(sB3 + 8);
             const bf16x8 wh = *(row_live ? ph : pz), wl = *(row_live ? pl : pz);
 #pragma unroll
-            for (int et = 0; et < 4; ++et) {
-                a3[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, as_bf16x8(ch[et]), a3[et], 0, 0, 0);
-                a3[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, as_bf16x8(cl[et]), a3[et], 0, 0, 0);
-                a3[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, as_bf16x8(ch[et]), a3[et], 0, 0, 0);
-            }
+            for (int term = 0; term < 3; ++term)            // term outermost: consecutive MFMAs on different accumulators
+#pragma unroll
+                for (int et = 0; et < 4; ++et)
+                    a3[et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(term == 0 ? wl : wh, as_bf16x8(term == 1 ? cl[et] : ch[et]), a3[et], 0, 0, 0);
         });
     if (g == 0) {
 #pragma unroll
@@ -578,15 +586,17 @@ __device__ __forceinline__ void ac_fast_layer1(const char *blob, const float *st
         float a[3];
 #pragma unroll
         for (int s = 0; s < 3; ++s) a[s] = sW1[(16 * rt + c) * kLdW1 + 4 * s + g];
+        f32x4 acc[4] = {bias, bias, bias, bias};              // k-step outermost: consecutive MFMAs on different accumulators
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int et = 0; et < 4; ++et) acc[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], xb[s][et], acc[et], 0, 0, 0);
 #pragma unroll
         for (int et = 0; et < 4; ++et) {
-            f32x4 acc = bias;
-#pragma unroll
-            for (int s = 0; s < 3; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], xb[s][et], acc, 0, 0, 0);
 #pragma unroll
             for (int pr = 0; pr < 2; ++pr) {
                 uint32_t h, l;
-                relu_split_pair(acc[2 * pr], acc[2 * pr + 1], h, l);
+                relu_split_pair(acc[et][2 * pr], acc[et][2 * pr + 1], h, l);
                 bh[rt >> 1][et][2 * (rt & 1) + pr] = h;
                 bl[rt >> 1][et][2 * (rt & 1) + pr] = l;
             }
@@ -630,11 +640,10 @@ __device__ __forceinline__ void ac_fast_branch_pass(const char *blob, int zeros,
             const bf16x8 wh = *reinterpret_cast<const bf16x8 *>(a3_base + q * (BR == 0 ? 256 : 64));
             const bf16x8 wl = *reinterpret_cast<const bf16x8 *>(a3_base + q * (BR == 0 ? 256 : 64) + (BR == 0 ? 1024 : 256));
 #pragma unroll
-            for (int et = 0; et < QS_SPLIT_NET; ++et) {
-                a3[E0 + et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl, as_bf16x8(ch[et]), a3[E0 + et], 0, 0, 0);
-                a3[E0 + et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, as_bf16x8(cl[et]), a3[E0 + et], 0, 0, 0);
-                a3[E0 + et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh, as_bf16x8(ch[et]), a3[E0 + et], 0, 0, 0);
-            }
+            for (int term = 0; term < 3; ++term)            // term outermost: consecutive MFMAs on different accumulators
+#pragma unroll
+                for (int et = 0; et < QS_SPLIT_NET; ++et)
+                    a3[E0 + et] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(term == 0 ? wl : wh, as_bf16x8(term == 1 ? cl[et] : ch[et]), a3[E0 + et], 0, 0, 0);
         });
 }
 
@@ -667,12 +676,14 @@ __device__ __forceinline__ void ac_exact_layer1(const AcLds &L, const float *sta
         float a[3];
 #pragma unroll
         for (int s = 0; s < 3; ++s) a[s] = L.W1[(16 * rt + c) * kLdW1 + 4 * s + g];
+        f32x4 acc[4] = {bias, bias, bias, bias};              // k-step outermost: consecutive MFMAs on different accumulators
+#pragma unroll
+        for (int s = 0; s < 3; ++s)
+#pragma unroll
+            for (int et = 0; et < 4; ++et) acc[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], xb[s][et], acc[et], 0, 0, 0);
 #pragma unroll
         for (int et = 0; et < 4; ++et) {
-            f32x4 acc = bias;
-#pragma unroll
-            for (int s = 0; s < 3; ++s) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[s], xb[s][et], acc, 0, 0, 0);
-            h1[rt][et] = relu4(acc);
+            h1[rt][et] = relu4(acc[et]);
         }
     }
 }
@@ -704,12 +715,13 @@ __device__ __forceinline__ void ac_exact_branch(const AcLds &L, const f32x4 (&h1
                     h2[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i], h1[rt][et][i], h2[et], 0, 0, 0);
         }
         const f32x4 w3 = *reinterpret_cast<const f32x4 *>(row_live ? w3row + 16 * nt : L.B3 + 8);
+        f32x4 r[4];
 #pragma unroll
-        for (int et = 0; et < 4; ++et) {
-            const f32x4 r = relu4(h2[et]);
+        for (int et = 0; et < 4; ++et) r[et] = relu4(h2[et]);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) a3[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[i], r[i], a3[et], 0, 0, 0);
-        }
+        for (int i = 0; i < 4; ++i)                     // k-step outermost: consecutive MFMAs on different accumulators
+#pragma unroll
+            for (int et = 0; et < 4; ++et) a3[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[i], r[et][i], a3[et], 0, 0, 0);
     }
 }
 
