@@ -569,23 +569,35 @@ __device__ __forceinline__ void mlp_actor_critic_fast(const float obs[12], float
 // steps the environments.  ac_fast_layer1: shared layer for the wave's 64 envs (observations read from the tile's LDS
 // stage, [k][env]), result = the B operands of BOTH 128 x 128 branches, kept in registers.  ac_fast_branch<BR>: one branch
 // (0 policy -> rows 0..3 of a3, 1 value -> row 4) over QS_SPLIT_NET env tiles per pass (256 registers per wave at two waves
-// per SIMD: next to the 128 operand registers the four-tile pass leaves a dozen loop-invariant values in scratch).
+// per SIMD: the four-tile pass fits next to the 128 operand registers once the LDS addresses share base registers, lds_opaque).
+// An LDS byte offset the optimiser cannot see through: everything addressed as `blob + opaque + constant` then shares ONE
+// address register with the constants in the instructions' offset fields, instead of one materialised address per constant
+// (the matrix wave has 256 registers for 128 operand registers plus its working set; such addresses went to scratch).
+__device__ __forceinline__ int lds_opaque(int off)
+{
+    asm volatile("" : "+v"(off));
+    return off;
+}
+
 __device__ __forceinline__ void ac_fast_layer1(const char *blob, const float *stage, int lane, u32x4 (&bh)[4][4], u32x4 (&bl)[4][4])
 {
-    const float *sW1 = reinterpret_cast<const float *>(blob + kAcFastW1);
-    const float *sB1 = reinterpret_cast<const float *>(blob + kAcFastB);
+    lane = lds_opaque(lane);       // lane-derived addresses are re-derived here every step instead of living across the step loop
     const int c = lane & 15, g = lane >> 4;
+    // one base register per array, the (row tile, k-step, env tile) part in the offset fields (see lds_opaque)
+    const float *w1 = reinterpret_cast<const float *>(blob + lds_opaque(kAcFastW1 + (c * kLdW1 + g) * 4));   // + 16 rt kLdW1 + 4 s
+    const float *b1 = reinterpret_cast<const float *>(blob + lds_opaque(kAcFastB + 16 * g));                  // + 16 rt
+    const float *xs = stage + lds_opaque(g * 64 + c);                                                         // + 256 s + 16 et
     float xb[3][4];
 #pragma unroll
     for (int s = 0; s < 3; ++s)
 #pragma unroll
-        for (int et = 0; et < 4; ++et) xb[s][et] = stage[(4 * s + g) * 64 + 16 * et + c];
+        for (int et = 0; et < 4; ++et) xb[s][et] = xs[256 * s + 16 * et];
 #pragma unroll
     for (int rt = 0; rt < 8; ++rt) {
-        const f32x4 bias = *reinterpret_cast<const f32x4 *>(sB1 + 16 * rt + 4 * g);
+        const f32x4 bias = *reinterpret_cast<const f32x4 *>(b1 + 16 * rt);
         float a[3];
 #pragma unroll
-        for (int s = 0; s < 3; ++s) a[s] = sW1[(16 * rt + c) * kLdW1 + 4 * s + g];
+        for (int s = 0; s < 3; ++s) a[s] = w1[16 * rt * kLdW1 + 4 * s];
         f32x4 acc[4] = {bias, bias, bias, bias};              // k-step outermost: consecutive MFMAs on different accumulators
 #pragma unroll
         for (int s = 0; s < 3; ++s)
@@ -609,20 +621,12 @@ __device__ __forceinline__ void ac_fast_layer1(const char *blob, const float *st
                             // but only two accumulators in flight -- a dependent v_mfma_f32_16x16x32_bf16 two instructions behind
                             // its producer waits for it (measured 22 cycles per MFMA against 18.5 with four)
 #endif
-// An LDS byte offset the optimiser cannot see through: everything addressed as `blob + opaque + constant` then shares ONE
-// address register with the constants in the instructions' offset fields, instead of one materialised address per constant
-// (the matrix wave has 256 registers for 128 operand registers plus its working set; 25 such addresses went to scratch).
-__device__ __forceinline__ int lds_opaque(int off)
-{
-    asm volatile("" : "+v"(off));
-    return off;
-}
-
 // zeros: byte offset (from blob) of 2 KiB of zeros -- what the dead rows of the output-layer A tiles read
 template <int BR, int E0>
 __device__ __forceinline__ void ac_fast_branch_pass(const char *blob, int zeros, const u32x4 (&bh)[4][4], const u32x4 (&bl)[4][4], int lane,
                                                     f32x4 (&a3)[4])
 {
+    lane = lds_opaque(lane);       // as in ac_fast_layer1
     const int c = lane & 15, g = lane >> 4;
     const char *bias_base = blob + lds_opaque(kAcFastB + 16 * g);                       // + 512 (1 + BR) + 64 nt
     // output-layer A fragments: rows 0..3 (policy, [q][row][g]) / row 4 (value, [q][g]) hold weights, every other row of the

@@ -914,8 +914,8 @@ __global__ __launch_bounds__(2 * kBlock, 1) void k_runner_split(StepArgs A, Runn
             const float v = sval[lane];
             __builtin_amdgcn_wave_barrier();
             if (active) {
-                if (t < A.T) R.values[t * A.n + env] = v;
-                else R.last_values[env] = v;                                  // model.value(obs) after the last step (ppo2.py:506)
+                float *vout = t < A.T ? R.values + t * A.n : R.last_values;   // last: model.value(obs) after the last step (ppo2.py:506)
+                vout[env] = v;
             }
             QS_PHASE(5);
         }
