@@ -193,28 +193,37 @@ __device__ __forceinline__ void mlp_actor_critic(const float obs[12], float out[
 #pragma unroll
         for (int et = 0; et < 4; ++et) a3[et] = bias3;
     }
-    const f32x4 zero = {0.0f, 0.0f, 0.0f, 0.0f};
+    // Source order = issue order (scheduling barriers): the weights of k-group G + 1 (16 MFMAs = 512 matrix cycles later) are
+    // requested before the MFMAs of group G, across tile and branch boundaries too; left alone, hipcc emits read -> wait ->
+    // MFMAs and exposes the LDS latency 4-5 times per tile.  The dead rows of the output-layer tile read 16 zero bytes
+    // (slots 8..11 of the padded b3): an address select, no branch in the MFMA stream.
+    auto w2_group = [&](int G) {                           // G = 64 br + 8 nt + rt
+        return *reinterpret_cast<const f32x4 *>(((G >> 6) ? L.W2v : L.W2p) + (16 * ((G >> 3) & 7) + c) * kLdW + 16 * (G & 7) + 4 * g);
+    };
+    f32x4 wbuf[2];
+    wbuf[0] = w2_group(0);
 #pragma unroll
     for (int br = 0; br < 2; ++br) {                       // 0: policy branch -> rows 0..3, 1: value branch -> row 4
-        const float *W2 = br ? L.W2v : L.W2p;
         const float *B2 = br ? L.B2v : L.B2p;
+        const bool row_live = br == 0 ? c < 4 : c == 4;
+        const float *w3row = br == 0 ? L.W3p + (c & 3) * kLdW + 4 * g : L.W3v + 4 * g;
 #pragma unroll
         for (int nt = 0; nt < 8; ++nt) {
             const f32x4 bias = *reinterpret_cast<const f32x4 *>(B2 + 16 * nt + 4 * g);
+            const f32x4 w3 = *reinterpret_cast<const f32x4 *>(row_live ? w3row + 16 * nt : L.B3 + 8);
             f32x4 h2[4] = {bias, bias, bias, bias};
 #pragma unroll
             for (int rt = 0; rt < 8; ++rt) {
-                const f32x4 w = *reinterpret_cast<const f32x4 *>(W2 + (16 * nt + c) * kLdW + 16 * rt + 4 * g);
+                const int G = 64 * br + 8 * nt + rt;
+                if (G + 1 < 128) wbuf[(G + 1) & 1] = w2_group(G + 1);
+                const f32x4 w = wbuf[G & 1];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
 #pragma unroll
                     for (int et = 0; et < 4; ++et)
                         h2[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i], h1[rt][et][i], h2[et], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
-            // output-layer A operand: row c of the 16-row tile; only rows 0..3 (policy) / row 4 (value) are non-zero
-            f32x4 w3 = zero;
-            if (br == 0) { if (c < 4) w3 = *reinterpret_cast<const f32x4 *>(L.W3p + c * kLdW + 16 * nt + 4 * g); }
-            else { if (c == 4) w3 = *reinterpret_cast<const f32x4 *>(L.W3v + 16 * nt + 4 * g); }
             f32x4 r[4];
 #pragma unroll
             for (int et = 0; et < 4; ++et) r[et] = relu4(h2[et]);
@@ -222,6 +231,7 @@ __device__ __forceinline__ void mlp_actor_critic(const float obs[12], float out[
             for (int i = 0; i < 4; ++i)                     // k-step outermost: consecutive MFMAs on different accumulators
 #pragma unroll
                 for (int et = 0; et < 4; ++et) a3[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[i], r[et][i], a3[et], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // rows 0..3 sit in lanes g == 0, row 4 in register 0 of lanes g == 1: hand them to the lane that owns the env
@@ -699,26 +709,34 @@ __device__ __forceinline__ void ac_exact_branch(const AcLds &L, const f32x4 (&h1
     const f32x4 bias3 = *reinterpret_cast<const f32x4 *>(L.B3 + 4 * g);
 #pragma unroll
     for (int et = 0; et < 4; ++et) a3[et] = bias3;
-    const float *W2 = BR ? L.W2v : L.W2p;
-    const float *B2 = BR ? L.B2v : L.B2p;
+    const float *W2 = (BR ? L.W2v : L.W2p) + c * kLdW + 4 * g;          // + 16 nt kLdW + 16 rt
+    const float *B2 = (BR ? L.B2v : L.B2p) + 4 * g;                     // + 16 nt
     // output-layer A operand: row c of the 16-row tile; only rows 0..3 (policy) / row 4 (value) are non-zero -- every other
     // row reads 16 zero bytes (slots 8..11 of the padded b3): an address select, no branch in the MFMA stream
     const bool row_live = BR == 0 ? c < 4 : c == 4;
     const float *w3row = BR == 0 ? L.W3p + (c & 3) * kLdW + 4 * g : L.W3v + 4 * g;
+    // Source order = issue order (scheduling barriers): the weights of k-group G + 1 (16 MFMAs = 512 matrix cycles later) are
+    // requested before the MFMAs of group G, across tile boundaries too; left alone, hipcc emits read -> wait -> MFMAs and
+    // exposes the LDS latency 4-5 times per tile (36.5 cycles per MFMA instead of the pipe's 32).
+    f32x4 wbuf[2];
+    wbuf[0] = *reinterpret_cast<const f32x4 *>(W2);
 #pragma unroll
     for (int nt = 0; nt < 8; ++nt) {
-        const f32x4 bias = *reinterpret_cast<const f32x4 *>(B2 + 16 * nt + 4 * g);
+        const f32x4 bias = *reinterpret_cast<const f32x4 *>(B2 + 16 * nt);
+        const f32x4 w3 = *reinterpret_cast<const f32x4 *>(row_live ? w3row + 16 * nt : L.B3 + 8);
         f32x4 h2[4] = {bias, bias, bias, bias};
 #pragma unroll
         for (int rt = 0; rt < 8; ++rt) {
-            const f32x4 w = *reinterpret_cast<const f32x4 *>(W2 + (16 * nt + c) * kLdW + 16 * rt + 4 * g);
+            const int G = 8 * nt + rt;
+            if (G + 1 < 64) wbuf[(G + 1) & 1] = *reinterpret_cast<const f32x4 *>(W2 + 16 * ((G + 1) >> 3) * kLdW + 16 * ((G + 1) & 7));
+            const f32x4 w = wbuf[G & 1];
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int et = 0; et < 4; ++et)
                     h2[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(w[i], h1[rt][et][i], h2[et], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        const f32x4 w3 = *reinterpret_cast<const f32x4 *>(row_live ? w3row + 16 * nt : L.B3 + 8);
         f32x4 r[4];
 #pragma unroll
         for (int et = 0; et < 4; ++et) r[et] = relu4(h2[et]);
@@ -726,6 +744,7 @@ __device__ __forceinline__ void ac_exact_branch(const AcLds &L, const f32x4 (&h1
         for (int i = 0; i < 4; ++i)                     // k-step outermost: consecutive MFMAs on different accumulators
 #pragma unroll
             for (int et = 0; et < 4; ++et) a3[et] = __builtin_amdgcn_mfma_f32_16x16x4f32(w3[i], r[et][i], a3[et], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
     }
 }
 
