@@ -298,8 +298,8 @@ __device__ __forceinline__ bf16x8 as_bf16x8(u32x4 w) { return __builtin_bit_cast
 // two branches as one sequence of 16), each 48 MFMAs over the four env tiles of the wave, followed by ReLU + hi/lo split into
 // the B operands of the output layer (`out_step(pair, ch, cl)` after every second tile = one k-step of 32 hidden units).
 // The tiles run as a software pipeline: the MFMAs of tile s + 1 are issued around the split of tile s, which depends only on
-// tile s's accumulators -- the split's VALU work then rides in the issue shadow of the MFMAs (16 matrix cycles each, 4 to
-// issue) instead of standing between two MFMA runs.  hipcc does not weave the two streams by itself (at this register
+// tile s's accumulators -- the split's VALU work then rides in the issue shadow of the MFMAs (16 matrix cycles each, 8 of
+// which hold the SIMD's vector-issue port) instead of standing between two MFMA runs.  hipcc does not weave the two streams by itself (at this register
 // pressure its scheduler falls back to source order, sched_group_barrier patterns included), so the source order IS the woven
 // order, pinned by scheduling barriers: MFMA m of tile s + 1 (order k-step | term | env tile, so that consecutive MFMAs use
 // different accumulators), then ONE instruction-sized piece of the split of tile s (pair m / 6, piece m % 6); the A fragments
