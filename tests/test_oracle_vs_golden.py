@@ -317,3 +317,48 @@ def test_numpy_twin_against_c_oracle_with_params(oracle64):
                 np.testing.assert_allclose(rec[i], r_c, rtol=1e-12, atol=1e-12)
                 np.testing.assert_allclose(obs[i], o_c, rtol=1e-11, atol=1e-11)
                 assert bool(done[i]) == d_c and int(flags[i]) == f_c
+
+
+@pytest.mark.parametrize("squash", [False, True])
+def test_actor_critic_restatement_against_independent_implementations(squash):
+    """oracle.pyoracle.actor_critic_step (the float64 restatement the GPU Runner kernels are held to; value / neglogp are
+    'parity unpinned' by reference outputs because TensorFlow is absent) against implementations it shares no code with: the
+    three-layer heads through torch.nn.functional.linear in float64, the diagonal-Gaussian neglogp through
+    scipy.stats.norm.logpdf, the tanh correction through log1p of the squared tanh; and its action mean against the actions
+    fixture g5 recorded from the reference env driven by the same weights (clip(mean) = the deterministic policy)."""
+    import os
+    import torch
+    from scipy.stats import norm
+    from conftest import GOLDEN
+    from oracle.pyoracle import actor_critic_step
+    with np.load(os.path.join(GOLDEN, "policy_best_model_v0.npz"), allow_pickle=False) as z:
+        W = {k: z[k] for k in z.files}
+    rng = np.random.RandomState(7)
+    obs = rng.uniform(-1.0, 1.0, (257, 12)) * np.array([3, 3, 3, 1, 1, 1, 0.5, 0.5, 0.5, 1, 1, 1.0])
+    noise = rng.standard_normal((257, 4))
+    u, value, neglogp, env_action, mean = actor_critic_step(W, obs, noise, squash=squash)
+    t = lambda k: torch.as_tensor(np.asarray(W[k], np.float64))                      # noqa: E731
+    F = torch.nn.functional
+    x = torch.as_tensor(obs)
+    h = F.relu(F.linear(x, t("w0").T, t("b0")))
+    mean_t = F.linear(F.relu(F.linear(h, t("w1").T, t("b1"))), t("w2").T, t("b2")).numpy()
+    value_t = F.linear(F.relu(F.linear(h, t("wv1").T, t("bv1"))), t("wv2").T, t("bv2")).numpy()[:, 0]
+    np.testing.assert_allclose(mean, mean_t, rtol=1e-12, atol=1e-13)
+    np.testing.assert_allclose(value, value_t, rtol=1e-12, atol=1e-13)
+    std = np.exp(np.asarray(W["logstd"], np.float64)).reshape(1, -1)
+    np.testing.assert_allclose(u, mean_t + std * noise, rtol=1e-13, atol=1e-14)
+    nl = -norm.logpdf(u, loc=mean_t, scale=std).sum(axis=1)
+    if squash:
+        nl = nl + np.log1p(-np.tanh(u) ** 2 + 1e-6).sum(axis=1)
+        np.testing.assert_allclose(env_action, np.tanh(u), rtol=0, atol=1e-15)
+    else:
+        np.testing.assert_allclose(env_action, np.clip(u, -1.0, 1.0), rtol=0, atol=0)
+    np.testing.assert_allclose(neglogp, nl, rtol=1e-11, atol=1e-11)
+    # the reference itself: fixture g5 = its env driven by clip(mean(obs)) of these weights (obs[t] is the observation AFTER
+    # step t; the episode starts from the nominal reset observation)
+    if not squash:
+        g5 = load_golden("g5_policy_episode")
+        first = np.zeros((1, 12)); first[0, 0] = 1.8
+        prev = np.concatenate([first, g5["obs"][:-1].astype(np.float64)])
+        _, _, _, _, m = actor_critic_step(W, prev, np.zeros((len(prev), 4)))
+        np.testing.assert_allclose(np.clip(m, -1, 1), g5["actions"], rtol=0, atol=5e-6)
