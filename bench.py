@@ -5,22 +5,32 @@
     (N > 1: run as is -- the parent spawns one child per GPU before it touches the GPU -- or under
      python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
 
-A "step" is one pass of the hot path over the batch: every env of this GPU stepped once through the step API
-(BASELINE.json config 3: 65 536 docking-v0 envs per GPU, U(-1,1) random actions already resident in HBM, rocRAND
-randomised auto-reset; state round-trips through HBM every step).  Envs shard over GPUs by env id with no data-path
-collective (scaling "weak": 65 536 envs per GPU); the RCCL all-gather of roll-out slabs that BASELINE configs 4/5
-mention is timed separately and reported under "allgather", never mixed into `value`.
+A "step" is one pass of the hot path over the batch: every env of this GPU stepped once through the step API (state
+round-trips through HBM every step, U(-1,1) random actions already resident in HBM, rocRAND randomised auto-reset).  The
+workload follows BASELINE.json's configs by GPU count unless --env / --envs-per-gpu / --randomise say otherwise:
+    N = 1, 2: config 3   65 536 docking-v0 envs per GPU, randomised init state            (392 B per env-step)
+    N = 4:    config 4   262 144 docking-v2 envs = 65 536 per GPU, randomised init state  (392 B)
+    N = 8:    config 5   1 048 576 docking-v2 envs = 131 072 per GPU, + per-env mass / inertia domain randomisation (408 B)
+Envs shard over GPUs by env id with no data-path collective (scaling "weak"); the RCCL all-gather of roll-out slabs that
+configs 4/5 name is timed separately and reported under "allgather", never mixed into `value`.
 
 ONE clock: `value`, `ms_per_step` and `roofline.achieved / frac / read_frac` all come from the same host wall-clock
 interval (barrier + synchronize on both sides, max over ranks).  The interval holds R back-to-back blocks of EXACTLY K
 steps (R chosen so that R*K >= --min-timed-steps): a 20-step interval is shorter than the synchronisation that closes it
-(~30 us), so the per-step time is only meaningful over a few thousand steps.  The HIP-event time of the same launches is
-reported separately as `roofline.gpu_timeline_*`, and the rocprofv3 kernel average from the committed profile as
-`roofline.rocprof_*`.
+(~30 us), so the per-step time is only meaningful over a few thousand steps.  Beside it, under their own names: the
+HIP-event time of the same launches (`roofline.gpu_timeline_*`), the in-kernel s_memrealtime timeline of the same chain
+from the committed stamped-build run (`roofline.stamp_*`) and the rocprofv3 kernel average of the committed profile
+(`roofline.rocprof_*`, computed from the launch shape that profile was TAKEN with -- its sidecar json).
 
-Prints ONE JSON line (rank 0).  Extra objects: "roofline", "parity" (fixture g4 = outputs of the NumPy reference
-replayed through qs_step), "cpu_baseline" (the C oracle on the host cores), "config1" (BASELINE config 1 on the CPU
-oracle), "rollout_fused", ...
+What the headline mode is and is not: with --queue-mode auto/private the timed loop is a pre-staged
+random-action ROLL-OUT -- qs_step packets back to back on the handle's private AQL queue(s), no end-of-kernel release, the
+outputs of a step consumable after the roll-out (qs_sync, or the stream-ordered hand-shake of qs_rollout_stepwise), not
+between two steps.  The rate a per-step `obs -> policy -> env.step` loop gets is `hip_stream_mode` (every launch releases)
+and `policy_between_steps`; `config.mode` / `config.outputs_consumable` say so in the line.
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline", "parity" (fixtures g4 / g5 / g7 / g1 = outputs of the NumPy
+reference replayed through the C ABI), "cpu_baseline" (the C oracle on the host cores + what the reference itself would
+reach there), "config1", "hip_stream_mode", "policy_between_steps", "rollout_stepwise", "step_api_131072_envs", ...
 """
 import argparse
 import json
@@ -36,7 +46,21 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec peak
 BYTES_PER_ENV_STEP = 392       # read 176 B + write 216 B per env-step (step-API mode)
 BYTES_PER_ENV_STEP_DR = 408    # + mass, Ixx, Iyy, Izz read (per-env params)
 READ_TARGET = 0.40             # north_star / SURVEY.md 8(d): >= 40 % of the HBM-read roofline <=> 18.2 G env-steps/s
-PROFILE_DIR = os.path.join(ROOT, "profiles", "r02")
+PROFILE_DIRS = [os.path.join(ROOT, "profiles", d) for d in ("r03", "r02")]    # newest first
+
+# BASELINE.json configs by GPU count (run_docking_ppo2.py:65-67 is the reference's only parallelism: envs over workers)
+CONFIGS = {
+    1: dict(tag="config 3", env="docking-v0", envs_per_gpu=65536, randomise=1,
+            text="65 536 parallel docking-v0 envs, random actions, SoA tiles + rocRAND randomised auto-reset"),
+    2: dict(tag="config 3 per GPU (x2)", env="docking-v0", envs_per_gpu=65536, randomise=1,
+            text="65 536 parallel docking-v0 envs per GPU, random actions, SoA tiles + rocRAND randomised auto-reset"),
+    4: dict(tag="config 4", env="docking-v2", envs_per_gpu=65536, randomise=1,
+            text="262 144 docking-v2 envs (moving target + random init) sharded over 4 GPUs = 65 536 per GPU; the RCCL all-gather "
+                 "of roll-out slabs is the separate `allgather` leg"),
+    8: dict(tag="config 5", env="docking-v2", envs_per_gpu=131072, randomise=2,
+            text="1 048 576 docking-v2 envs with per-env mass / inertia domain randomisation sharded over 8 GPUs = 131 072 per "
+                 "GPU (408 B per env-step); the RCCL all-gather of roll-out slabs is the separate `allgather` leg"),
+}
 
 
 def parse():
@@ -44,10 +68,10 @@ def parse():
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=2000)
     p.add_argument("--warmup", type=int, default=200)
-    p.add_argument("--envs-per-gpu", type=int, default=65536)
-    p.add_argument("--env", default="docking-v0", choices=["docking-v0", "docking-v2"])
+    p.add_argument("--envs-per-gpu", type=int, default=None, help="default: BASELINE's config for --gpus (see the docstring)")
+    p.add_argument("--env", default=None, choices=["docking-v0", "docking-v2"], help="default: by --gpus")
     p.add_argument("--integrator", default="frozen", choices=["frozen", "rk4"])
-    p.add_argument("--randomise", type=int, default=1, help="0 nominal resets, 1 rocRAND init state, 2 + mass/inertia")
+    p.add_argument("--randomise", type=int, default=None, help="0 nominal resets, 1 rocRAND init state, 2 + mass/inertia; default: by --gpus")
     p.add_argument("--action-pool", type=int, default=512, help="distinct pre-generated [N,4] action batches cycled")
     p.add_argument("--groups", type=int, default=-1,
                    help="env groups in flight (qs_set_groups): 1 = one launch per step; G > 1 = G chains on G streams, "
@@ -56,13 +80,14 @@ def parse():
     p.add_argument("--queues", type=int, default=2, help="private queues with --queue-mode private (1..4)")
     p.add_argument("--queue-mode", default="auto", choices=["auto", "hip", "private"],
                    help="private: step launches on an AQL queue owned by the handle, without HIP's end-of-kernel cache write-back "
-                        "(qs_set_queue_mode; bit-identical results); hip: ordinary launches on the HIP stream; auto: private if it "
-                        "opens AND reproduces the HIP-stream chain bit for bit on this machine, else hip")
+                        "(qs_set_queue_mode; bit-identical results; a pre-staged roll-out: outputs consumable after it, not per "
+                        "step); hip: ordinary launches on the HIP stream; auto: private if it opens AND reproduces the HIP-stream "
+                        "chain bit for bit on this machine, else hip")
     p.add_argument("--min-timed-steps", type=int, default=2000,
                    help="the timed interval holds R = ceil(this / K) back-to-back blocks of K steps")
     p.add_argument("--rollout-T", type=int, default=64, help="steps per launch of the fused roll-out leg")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    p.add_argument("--no-extras", action="store_true", help="skip the rollout_fused / rk4 / policy / allgather legs")
+    p.add_argument("--no-extras", action="store_true", help="skip every leg but the headline (and parity / cpu_baseline)")
     p.add_argument("--no-parity", action="store_true")
     p.add_argument("--cpu-seconds", type=float, default=12.0)
     p.add_argument("--repeats", type=int, default=3, help="timed intervals; the median one is reported")
@@ -70,7 +95,17 @@ def parse():
                    help="nccl (= RCCL over xGMI, the real thing) or gloo (rehearsal of the multi-rank control flow, "
                         "e.g. several ranks sharing one GPU; skips the all-gather leg)")
     p.add_argument("--spawn-timeout", type=float, default=1500.0)
-    return p.parse_args()
+    args = p.parse_args()
+    cfg = CONFIGS.get(args.gpus, CONFIGS[2] if args.gpus < 4 else (CONFIGS[4] if args.gpus < 8 else CONFIGS[8]))
+    args.config_tag = cfg["tag"] if (args.env is None and args.envs_per_gpu is None and args.randomise is None) else None
+    args.config_text = cfg["text"]
+    if args.env is None:
+        args.env = cfg["env"]
+    if args.envs_per_gpu is None:
+        args.envs_per_gpu = cfg["envs_per_gpu"]
+    if args.randomise is None:
+        args.randomise = cfg["randomise"]
+    return args
 
 
 DEFAULT_GROUPS = 1   # measured on MI355X (profiles/r02/groups_sweep.txt): more chains in flight do not raise the rate
@@ -170,6 +205,20 @@ def cpu_baseline(kind, seconds, seed=1234):
             k += 1
     out["numpy_twin"] = {"value": k * 4096 / (time.perf_counter() - t0), "unit": "env-steps/s", "cores": 1,
                          "what": "oracle/np_oracle.py, float64, 4 096 envs per vectorised call"}
+    # relate the port's rate to the TRUE reference.  oracle/calibrate_cpu.py measured, on one core of
+    # the build container (where the reference can be imported), port rate / reference rate; the reference itself would
+    # therefore reach about value / ratio on these host cores.
+    try:
+        with open(os.path.join(ROOT, "oracle", "cpu_calibration.json")) as f:
+            cal = json.load(f)
+        c = cal["docking-v0" if kind == 0 else "docking-v2"]
+        out["reference_equivalent"] = {"value": out["value"] / c["ratio"], "unit": "env-steps/s", "cores": cores,
+                                       "ratio_port_over_reference": c["ratio"],
+                                       "reference_env_steps_per_s_one_core": c["reference_env_steps_per_s"],
+                                       "source": "oracle/cpu_calibration.json (oracle/calibrate_cpu.py: C oracle vs the imported "
+                                                 "NumPy/SciPy reference, one core, build container, %s)" % cal["host"].get("cpu", "?")}
+    except (OSError, KeyError, ValueError):
+        out["reference_equivalent"] = None
     return out
 
 
@@ -224,62 +273,137 @@ def config1_cpu(seconds=2.0):
 # parity: the BASELINE metric's second half ("per-step state L2 err vs NumPy ref")
 # --------------------------------------------------------------------------------------------------------------------
 def parity_vs_reference(qa, device):
-    """Replays fixture g4 (1 500 steps each of docking-v0 and docking-v2 recorded from the imported NumPy reference by
-    oracle/gen_goldens.py, full internal state before and after every step) through qs_step: step s becomes env s of one
-    batch, inputs rounded to float32, ONE fused step, outputs compared with the reference's own.  Outside the timed
-    region; the oracle is not involved."""
+    """The metric's second half, for every fixture family the reference produced (oracle/gen_goldens.py), replayed through
+    the C ABI with inputs rounded to float32 -- each recorded reference step becomes env s of ONE batch and is stepped once:
+      g4  1 500 steps each of docking-v0 / -v2 under random and near-hover actions (27 + 13 episodes, over-limit ends)
+      g5  the 600-step docking-v0 episode driven by the shipped policy: 183 docked steps, ends by time-out
+      g7  six trajectories with patched mass / inertia (per-env params path), v0 and v2
+      g1  2 500 adversarial Drone.step cases: 1 712 attitude-limiter hits, 1 166 active rotor clamps (qs_drone_step)
+    Outside the timed region; the oracle is not involved."""
     import numpy as np
-    out = {"source": "tests/golden/g4_traj_v{0,2}.npz = outputs of the NumPy reference (oracle/gen_goldens.py)",
+    gold = os.path.join(ROOT, "tests", "golden")
+    out = {"source": "tests/golden/g{4,5,7,1}*.npz = outputs of the NumPy reference (oracle/gen_goldens.py)",
            "tolerance": "north_star: 1e-5 relative per step (float32)"}
     worst = {"state_l2_rel": 0.0, "obs_l2_rel": 0.0, "reward_abs_scaled": 0.0}
-    for name, env_id in (("g4_traj_v0", "docking-v0"), ("g4_traj_v2", "docking-v2")):
-        path = os.path.join(ROOT, "tests", "golden", name + ".npz")
-        if not os.path.exists(path):
-            return None
-        with np.load(path) as z:
-            g = {k: z[k] for k in z.files}
-        n = len(g["rec_before"])
+    l2 = lambda a, b: np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(b, axis=1), 1e-30)   # noqa: E731
+
+    def env_family(g, env_id, prefix="", par=None):
+        n = len(g[prefix + "rec_before"])
         env = qa.VecDockingEnv(env_id, num_envs=n, device=device, auto_reset=False)
-        rec = g["rec_before"].astype(np.float32)
+        rec = g[prefix + "rec_before"].astype(np.float32)
         env.set_state(chaser=rec[:, 0:13], target=rec[:, 13:26], u_prev=rec[:, 26:34], qdes=rec[:, 34:38],
                       last_shaping=rec[:, 38], t=rec[:, 39])
-        obs, rew, done, infos = env.step(g["actions"].astype(np.float32))
+        if par is not None:
+            env.set_params(np.full(n, par[0], np.float32), np.tile(np.asarray(par[1:4], np.float32), (n, 1)))
+        obs, rew, done, infos = env.step(g[prefix + "actions"].astype(np.float32))
+        flags = infos.flags
         st = env.get_state()
         obs, rew, done = obs.cpu().numpy().astype(np.float64), rew.cpu().numpy().astype(np.float64), done.cpu().numpy()
         env.close()
-        ref = g["rec_after"]
-        l2 = lambda a, b: np.linalg.norm(a - b, axis=1) / np.maximum(np.linalg.norm(b, axis=1), 1e-30)   # noqa: E731
+        ref = g[prefix + "rec_after"]
         e_c = l2(st["chaser"].astype(np.float64), ref[:, 0:13])
         e_t = l2(st["target"].astype(np.float64), ref[:, 13:26])
-        e_o = l2(obs, g["obs"])
-        e_r = np.abs(rew - g["reward"]) / np.maximum(1.0, np.abs(ref[:, 38]))
+        e_o = l2(obs, g[prefix + "obs"])
+        e_r = np.abs(rew - g[prefix + "reward"]) / np.maximum(1.0, np.abs(ref[:, 38]))
         # done / flags are decided by thresholds: exclude the steps the reference itself decides within 1e-4 of one
         rmax = 3.0 if env_id == "docking-v0" else 10.0
-        npos = np.linalg.norm(g["obs"][:, 0:3], axis=1)
+        npos = np.linalg.norm(g[prefix + "obs"][:, 0:3], axis=1)
+        nvel = np.linalg.norm(g[prefix + "obs"][:, 3:6], axis=1)
         margin = np.minimum(np.abs(npos - rmax), np.abs(ref[:, 2] - 0.1))
-        flips = int(np.sum((done != g["done"].astype(bool)) & (margin > 1e-4)))
-        out[env_id] = {"steps": n, "chaser_state_l2_rel_max": float(e_c.max()), "target_state_l2_rel_max": float(e_t.max()),
-                       "state_l2_rel_mean": float(0.5 * (e_c.mean() + e_t.mean())), "obs_l2_rel_max": float(e_o.max()),
-                       "obs_l2_rel_mean": float(e_o.mean()), "reward_abs_over_max1shaping_max": float(e_r.max()),
-                       "done_flips_outside_1e-4_margin": flips}
-        worst["state_l2_rel"] = max(worst["state_l2_rel"], float(e_c.max()), float(e_t.max()))
-        worst["obs_l2_rel"] = max(worst["obs_l2_rel"], float(e_o.max()))
-        worst["reward_abs_scaled"] = max(worst["reward_abs_scaled"], float(e_r.max()))
+        flips = int(np.sum((done != g[prefix + "done"].astype(bool)) & (margin > 1e-4)))
+        dmargin = np.minimum(np.minimum(np.abs(npos - 0.1), np.abs(nvel - 0.1)),
+                             np.min(np.abs(np.abs(g[prefix + "obs"][:, 6:9]) - np.deg2rad(10.0)), axis=1))
+        dock_flips = int(np.sum(((flags & 1) != (g[prefix + "flags"].astype(np.uint8) & 1)) & (dmargin > 1e-4)))
+        r = {"steps": n, "chaser_state_l2_rel_max": float(e_c.max()), "target_state_l2_rel_max": float(e_t.max()),
+             "state_l2_rel_mean": float(0.5 * (e_c.mean() + e_t.mean())), "obs_l2_rel_max": float(e_o.max()),
+             "obs_l2_rel_mean": float(e_o.mean()), "reward_abs_over_max1shaping_max": float(e_r.max()),
+             "done_flips_outside_1e-4_margin": flips, "docked_flag_flips_outside_1e-4_margin": dock_flips,
+             "docked_steps": int((flags & 1).sum()), "done_steps": int(done.sum())}
+        worst["state_l2_rel"] = max(worst["state_l2_rel"], r["chaser_state_l2_rel_max"], r["target_state_l2_rel_max"])
+        worst["obs_l2_rel"] = max(worst["obs_l2_rel"], r["obs_l2_rel_max"])
+        worst["reward_abs_scaled"] = max(worst["reward_abs_scaled"], r["reward_abs_over_max1shaping_max"])
+        return r
+
+    def load(name):
+        path = os.path.join(gold, name + ".npz")
+        if not os.path.exists(path):
+            return None
+        with np.load(path) as z:
+            return {k: z[k] for k in z.files}
+
+    fams, flips_total = {}, 0
+    for name, env_id in (("g4_traj_v0", "docking-v0"), ("g4_traj_v2", "docking-v2")):
+        g = load(name)
+        if g is None:
+            return None
+        fams.setdefault("g4_trajectories", {})[env_id] = env_family(g, env_id)
+    g = load("g5_policy_episode")
+    if g is not None:
+        fams["g5_policy_episode_docked_and_timeout"] = env_family(g, "docking-v0")
+    g = load("g7_domain_rand")
+    if g is not None:
+        fams["g7_mass_inertia"] = {}
+        for kind, env_id in ((0, "docking-v0"), (1, "docking-v2")):
+            for j in range(3):
+                key = "k%d_s%d_" % (kind, j)
+                fams["g7_mass_inertia"]["%s/set%d" % (env_id, j)] = env_family(g, env_id, prefix=key, par=g[key + "par"])
+    g = load("g1_drone_step")
+    if g is not None:
+        s2, up2, lim = qa.drone_step_batch(g["state"], g["u_prev"], g["u"], dt=float(g["dt"]), device=device)
+        safe = g["margin"] > 1e-4                # fp32 cannot decide a limiter knife-edge closer than this
+        e_s = l2(s2[safe].astype(np.float64), g["state_out"][safe])
+        e_u = np.abs(up2[safe].astype(np.float64) - g["u_prev_out"][safe]).max(axis=1) / np.maximum(1.0, np.abs(g["u_prev_out"][safe]).max(axis=1))
+        fams["g1_drone_step_limiter_and_clamps"] = {
+            "cases": int(safe.sum()), "limiter_hits": int(g["limited"][safe].sum()),
+            "limiter_flag_mismatches_outside_1e-4_margin": int(np.sum(lim[safe] != g["limited"][safe].astype(bool))),
+            "state_l2_rel_max": float(e_s.max()), "state_l2_rel_mean": float(e_s.mean()), "limited_control_abs_scaled_max": float(e_u.max())}
+        worst["state_l2_rel"] = max(worst["state_l2_rel"], float(e_s.max()))
+    out["families"] = fams
+
+    def walk(d):
+        for v in d.values():
+            if isinstance(v, dict):
+                if "done_flips_outside_1e-4_margin" in v:
+                    yield v["done_flips_outside_1e-4_margin"] + v["docked_flag_flips_outside_1e-4_margin"]
+                else:
+                    yield from walk(v)
+    flips_total = sum(walk(fams)) + fams.get("g1_drone_step_limiter_and_clamps", {}).get("limiter_flag_mismatches_outside_1e-4_margin", 0)
     out.update(worst)
-    out["within_tolerance"] = bool(worst["state_l2_rel"] <= 1e-5 and worst["obs_l2_rel"] <= 1e-5 and worst["reward_abs_scaled"] <= 2e-5)
+    out["decision_flips_outside_margin"] = int(flips_total)
+    out["within_tolerance"] = bool(worst["state_l2_rel"] <= 1e-5 and worst["obs_l2_rel"] <= 1e-5 and worst["reward_abs_scaled"] <= 2e-5
+                                   and flips_total == 0)
     return out
 
 
 # --------------------------------------------------------------------------------------------------------------------
-def rocprof_kernel_average(kernel_substr, fname="step_api_kernel_stats.csv"):
-    """average duration (us) of the step kernel in the committed `rocprofv3 --kernel-trace --stats` summary"""
+def profile_file(fname):
+    """newest committed profile directory that holds fname"""
+    for d in PROFILE_DIRS:
+        path = os.path.join(d, fname)
+        if os.path.exists(path):
+            return path
+    return None
+
+
+def rocprof_kernel_average(kernel_substr, fname):
+    """(average us, calls, relative path, sidecar dict) of the step kernel in a committed `rocprofv3 --kernel-trace --stats`
+    summary.  The sidecar <fname minus .csv>.json records the launch shape the profile was TAKEN with (queue mode, queues, envs
+    per launch): the bytes of one launch come from there, never from what this run happens to use."""
     import csv
-    path = os.path.join(PROFILE_DIR, fname)
+    path = profile_file(fname)
+    if not path:
+        return None
+    side = {}
+    try:
+        with open(path[:-4] + ".json") as f:
+            side = json.load(f)
+    except (OSError, ValueError):
+        pass
     try:
         with open(path) as f:
             for row in csv.DictReader(f):
                 if kernel_substr in row.get("Name", ""):
-                    return float(row["AverageNs"]) / 1e3, int(row["Calls"]), os.path.relpath(path, ROOT)
+                    return float(row["AverageNs"]) / 1e3, int(row["Calls"]), os.path.relpath(path, ROOT), side
     except (OSError, KeyError, ValueError):
         pass
     return None
@@ -332,8 +456,9 @@ def main():
     kind = 0 if args.env == "docking-v0" else 1
     groups = DEFAULT_GROUPS if args.groups < 0 else max(1, args.groups)
 
-    def make_env(integrator, num=n, offset=lo):
-        return VecDockingEnv(args.env, num_envs=num, device=local_rank, integrator=integrator, randomise=args.randomise,
+    def make_env(integrator, num=n, offset=lo, env_id=None, randomise=None):
+        return VecDockingEnv(env_id or args.env, num_envs=num, device=local_rank, integrator=integrator,
+                             randomise=args.randomise if randomise is None else randomise,
                              seed=1234, env_id_offset=offset, init_range=C3_INIT_RANGE, mass_scale=(0.8, 1.2),
                              inertia_scale=(0.8, 1.2), copy=False)
 
@@ -382,14 +507,14 @@ def main():
             dist.barrier()
         return max_over_ranks(wall), ev_ms
 
-    def verify_private_queue(pool, queues=1):
+    def verify_private_queue(mk, pool, queues=1):
         """The private-queue mode rests on hardware behaviour HIP does not promise (block -> XCD placement).  Before it is
-        used for the headline it has to open on this machine AND reproduce the HIP-stream chain bit for bit: two fresh envs,
+        used for a timed leg it has to open on this machine AND reproduce the HIP-stream chain bit for bit: two fresh envs,
         the same 96 steps (auto-resets included), every output of the last step and the whole final state compared."""
-        a, b = make_env(args.integrator), make_env(args.integrator)
+        a, b = mk(), mk()
         try:
             a.reset(); b.reset()
-            b.set_queue_mode(True, queues)
+            b.set_queue_mode(True, queues, ordering="host")
             for k in range(96):
                 oa, ra, da, _ = a.step(pool[k % pool.shape[0]])
                 ob, rb, db, _ = b.step(pool[k % pool.shape[0]])
@@ -403,40 +528,42 @@ def main():
         finally:
             a.close(); b.close()
 
+    def pick_launch_path(env, mk, pool, probe):
+        """candidates: the HIP stream and 1..3 private queues (host-ordered: pre-staged actions); each private candidate has to
+        pass the bit-identity check on THIS machine on every rank, and the fastest one on a short probe is used (the private
+        queues lose above ~200 000 envs, where the state outgrows the L2s).  -> (queue_mode, queues, note); env is left in it"""
+        if args.queue_mode == "hip" or groups > 1:
+            return "hip", 0, None
+        cand = [int(args.queues)] if args.queue_mode == "private" else [1, 2, 3]
+        best_t = time_steps(env, probe, 1, 50, pool)[0] if args.queue_mode == "auto" else float("inf")
+        notes, queues = [], 0
+        for q in cand:
+            ok, why = verify_private_queue(mk, pool, q)
+            if -max_over_ranks(-float(ok)) < 0.5:          # every rank must agree (the legs below hold collective barriers)
+                notes.append("%d private queue(s) not used: %s" % (q, why if not ok else "another rank could not verify it"))
+                if args.queue_mode == "private":
+                    raise SystemExit("--queue-mode private: " + notes[-1])
+                continue
+            env.set_queue_mode(True, q, ordering="host")
+            t = time_steps(env, probe, 1, 50, pool)[0]
+            notes.append("%d private queue(s): %.2f us per step on the probe" % (q, t / probe * 1e6))
+            if t < best_t:
+                best_t, queues = t, q
+        if queues:
+            env.set_queue_mode(True, queues, ordering="host")
+        else:
+            env.set_queue_mode(False)
+        return ("private" if queues else "hip"), queues, "; ".join(notes)
+
     K, W = args.steps, args.warmup
     R = max(1, -(-args.min_timed_steps // K))
     env = make_env(args.integrator)
     env.reset()
     if groups > 1:
         groups = env.set_groups(groups, threads=bool(args.group_threads))
-    P = max(1, min(args.action_pool, K * R))
+    P = max(1, min(args.action_pool, K * R, (1 << 29) // (n * 16)))      # at most 512 MiB of action batches
     pool = env.random_actions(P, step0=0)               # [P,N,4] U(-1,1), resident in HBM before timing
-    queue_mode, queue_note, queues = "hip", None, 0
-    if args.queue_mode != "hip" and groups <= 1:
-        # candidates: the HIP stream and 1..3 private queues; each private candidate has to pass the bit-identity check, and the
-        # fastest one on a short probe is used (the private queues lose above ~200 000 envs, where the state outgrows the L2s)
-        cand = [int(args.queues)] if args.queue_mode == "private" else [1, 2, 3]
-        probe = max(200, min(1000, K))
-        best_t = time_steps(env, probe, 1, 50, pool)[0] if args.queue_mode == "auto" else float("inf")
-        notes = []
-        for q in cand:
-            ok, why = verify_private_queue(pool, q)
-            if -max_over_ranks(-float(ok)) < 0.5:          # every rank must agree (the legs below hold collective barriers)
-                notes.append("%d private queue(s) not used: %s" % (q, why if not ok else "another rank could not verify it"))
-                if args.queue_mode == "private":
-                    raise SystemExit("--queue-mode private: " + notes[-1])
-                continue
-            env.set_queue_mode(True, q)
-            t = time_steps(env, probe, 1, 50, pool)[0]
-            notes.append("%d private queue(s): %.2f us per step on the probe" % (q, t / probe * 1e6))
-            if t < best_t:
-                best_t, queues = t, q
-        if queues:
-            env.set_queue_mode(True, queues)
-            queue_mode = "private"
-        else:
-            env.set_queue_mode(False)
-        queue_note = "; ".join(notes)
+    queue_mode, queues, queue_note = pick_launch_path(env, lambda: make_env(args.integrator), pool, max(200, min(1000, K)))
     runs = [time_steps(env, K, R, W, pool, groups) for _ in range(max(1, args.repeats))]
     order = sorted(range(len(runs)), key=lambda i: runs[i][0])
     wall, ev_ms = runs[order[len(order) // 2]]
@@ -449,18 +576,29 @@ def main():
     ev_us = ev_ms * 1e3 / steps_timed
     split = n <= 131072
     kname = "k_env_split" if split else "k_env<"
+    frac_of = lambda us, b=bpe, nn=n: b * nn / (us * 1e-6) / 1e9 / HBM_PEAK_GBS      # noqa: E731
 
     if groups > 1:
         mode_text = ("step-API: one qs_step_groups call per step = %d launches (env groups of %d envs on %d streams, %s), "
                      "bit-identical to qs_step" % (groups, n // groups, groups, "one launcher thread per group" if args.group_threads
                                                    else "issued by the calling thread"))
+        consumable = "per step, in stream order (qs_groups_join)"
     elif queue_mode == "private":
-        mode_text = ("step-API: one qs_step call per step = one AQL packet per private queue of the handle (%d queue(s), each "
-                     "stepping a contiguous range of tiles; a packet is ordered behind the previous step of its queue, acquires at "
-                     "agent scope and carries NO end-of-kernel release: a tile's state stays in the L2 of the XCD that steps it; "
-                     "verified bit-identical to the HIP-stream chain on this machine before timing)" % queues)
+        mode_text = ("step-API, pre-staged random-action ROLL-OUT: one qs_step call per step = one AQL packet per private queue of "
+                     "the handle (%d queue(s), each stepping a contiguous range of tiles; a packet is ordered behind the previous step "
+                     "of its queue, acquires at agent scope and carries NO end-of-kernel release: a tile's state stays in the L2 of the "
+                     "XCD that steps it; verified bit-identical to the HIP-stream chain on this machine before timing; requires the "
+                     "hardware's round-robin workgroup->XCD placement, checked per tile in-kernel, else the handle fails loudly and "
+                     "`hip_stream_mode` is what remains)" % queues)
+        consumable = ("after the roll-out (qs_sync, or the stream-ordered hand-shake of qs_rollout_stepwise: `rollout_stepwise`), NOT "
+                      "between two steps; a per-step obs -> policy -> env.step loop runs at `hip_stream_mode` / `policy_between_steps`")
     else:
         mode_text = "step-API: one qs_step launch per step on the HIP stream"
+        consumable = "per step, in stream order"
+    tag = args.config_tag
+    workload = ("BASELINE %s: %s" % (tag, args.config_text)) if tag else (
+        "custom (flags override BASELINE's config for %d GPU(s)): %d parallel %s envs per GPU, U(-1,1) random actions, randomise %d"
+        % (world, n, args.env, args.randomise))
     out = {
         "metric": "env-steps/sec at N parallel envs (1/2/4/8 GPU); per-step state L2 err vs NumPy ref",
         "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": W,
@@ -471,12 +609,11 @@ def main():
                                    "synchronize; value, ms_per_step and roofline.frac all derive from this one wall clock"
                                    % (len(runs), W, R, K),
                          "env_steps_per_s_all_intervals": [total_envs * steps_timed / r[0] for r in runs]},
-        "config": {"workload": "BASELINE config 3: %d parallel %s envs per GPU, U(-1,1) random actions, SoA tiles + "
-                               "rocRAND randomised auto-reset" % (n, args.env),
+        "config": {"workload": workload, "baseline_config": tag,
                    "envs_per_gpu": n, "total_envs": total_envs, "env": args.env, "integrator": args.integrator,
-                   "dt": 0.02, "randomise": args.randomise,
+                   "dt": 0.02, "randomise": args.randomise, "action_pool_batches": P,
                    "queue_mode": queue_mode, "private_queues": queues,
-                   "mode": mode_text,
+                   "mode": mode_text, "outputs_consumable": consumable,
                    "groups": groups,
                    "parallelism": "env-sharded x%d, no data-path collective" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -485,37 +622,60 @@ def main():
                                + (", dispatched from the handle's private AQL queue" if queue_mode == "private" else ""),
                      "bytes_per_env_step": bpe, "bytes_per_step": bpe * n, "launches_per_step": max(groups, queues, 1),
                      "step_period_us": step_us,
-                     "read_frac": rbpe * n / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                     "read_frac": frac_of(step_us, rbpe),
                      "read_frac_target": READ_TARGET,
-                     "read_frac_target_met": bool(rbpe * n / (step_us * 1e-6) / 1e9 / HBM_PEAK_GBS >= READ_TARGET),
+                     "read_frac_target_met": bool(frac_of(step_us, rbpe) >= READ_TARGET),
                      "gpu_timeline_us_per_step": ev_us,
-                     "gpu_timeline_frac": bpe * n / (ev_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                     "gpu_timeline_frac": frac_of(ev_us),
                      "basis": "achieved = %d B x %d envs / wall time per step (the SAME clock as value and ms_per_step); "
                               "gpu_timeline_* = HIP events around the same launches; working set %.1f MB is "
                               "Infinity-Cache resident" % (bpe, n, n * 160 / 1e6)},
     }
-    # rocprofv3 kernel average of the same command (committed summary): per-launch duration of the step kernel
-    rp = rocprof_kernel_average(kname)
-    if rp and n == 65536 and args.env == "docking-v0" and args.integrator == "frozen" and args.randomise == 1:
-        avg_us, calls, src = rp
-        per_launch_bytes = bpe * n / max(groups, queues, 1)
-        out["roofline"].update({"rocprof_kernel_avg_us": avg_us, "rocprof_calls": calls, "rocprof_source": src,
-                                "rocprof_kernel_frac": per_launch_bytes / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                                "rocprof_note": "bytes of ONE launch (%d envs) / its average duration in the profiled process "
-                                                "(`rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 500 --warmup 50 "
-                                                "--no-extras ...`; the profiler wraps every queue and adds a completion signal per "
-                                                "dispatch: the profiled process steps at ~7 us, not %.2f us)" % (n // max(groups, queues, 1), step_us)})
+    c3_shape = n == 65536 and args.env == "docking-v0" and args.integrator == "frozen" and args.randomise == 1
+    # (1) in-kernel timeline of the SAME chain from the committed stamped-build run (tools/stamp_timeline.py: s_memrealtime
+    #     stamps held in registers; unlike rocprofv3 they leave the queue alone)
+    sp = profile_file("step_kernel_timeline_private_q%d.json" % queues) if queue_mode == "private" else profile_file("step_kernel_timeline_hip.json")
+    if sp and c3_shape:
+        try:
+            with open(sp) as f:
+                st = json.load(f)
+            out["roofline"].update({"stamp_period_us": st["stamp_period_us"], "stamp_kernel_span_us": st["stamp_kernel_span_us"],
+                                    "stamp_gap_us": st["stamp_gap_us"], "stamp_frac": frac_of(st["stamp_period_us"]),
+                                    "stamp_source": os.path.relpath(sp, ROOT),
+                                    "stamp_note": "light stamped build (-DQS_STAMP=2: first / last s_memrealtime of each wave), %s, %d-batch "
+                                                  "action pool; period = first workgroup start -> next step's first start, span = first start "
+                                                  "-> last wave drained" % ("%d private queue(s)" % st["queues"] if st.get("queues") else "HIP stream",
+                                                                            st.get("action_pool", 0))})
+        except (OSError, KeyError, ValueError):
+            pass
+    # (2) rocprofv3 kernel averages of the committed profiles: per-launch duration of the step kernel, with the bytes of ONE
+    #     launch taken from the shape the profile was TAKEN with (sidecar json), not from this run's queue count
+    if c3_shape:
+        for key, fname in (("rocprof_private", "step_api_kernel_stats_private.csv"), ("rocprof_hip_stream", "step_api_kernel_stats_hip.csv"),
+                           ("rocprof", "step_api_kernel_stats.csv")):
+            rp = rocprof_kernel_average(kname, fname)
+            if not rp or (key == "rocprof" and "rocprof_private" in out["roofline"]):
+                continue
+            avg_us, calls, src, side = rp
+            envs_per_launch = int(side.get("envs_per_launch", n // max(int(side.get("queues", 1)), 1)))
+            out["roofline"][key] = {"kernel_avg_us": avg_us, "calls": calls, "source": src,
+                                    "envs_per_launch": envs_per_launch, "profiled_queue_mode": side.get("queue_mode", "private"),
+                                    "profiled_queues": side.get("queues", 1),
+                                    "kernel_frac": bpe * envs_per_launch / (avg_us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                    "note": side.get("note", "bytes of ONE launch / its average duration in the profiled process; rocprofv3 "
+                                                             "wraps every HSA queue and adds a completion signal per dispatch, so a "
+                                                             "private-queue launch is slower under the profiler than in this run")}
     # HBM-side bytes per step from the PMC passes (collected separately: rocprofv3 --pmc cannot run inside
     # this process); only quoted when the profile was taken on this very configuration
     try:
-        pmc = json.load(open(os.path.join(PROFILE_DIR, "pmc_traffic.json")))
-        if pmc["envs"] == n and args.env == "docking-v0" and args.integrator == "frozen" and args.randomise == 1:
+        pmc = json.load(open(profile_file("pmc_traffic.json")))
+        if pmc["envs"] == n and c3_shape:
             src = pmc["private_queue"] if queue_mode == "private" and "private_queue" in pmc else pmc
             out["roofline"]["traffic"] = src["traffic_bytes_per_step"]
             out["roofline"]["traffic_source"] = pmc["source"] + ("; " + src["note"] if "note" in src else "")
             if src is not pmc:
                 out["roofline"]["traffic_hip_stream_mode"] = pmc["traffic_bytes_per_step"]
-    except (OSError, ValueError, KeyError):
+    except (OSError, ValueError, KeyError, TypeError):
         pass
 
     if queue_note:
@@ -525,140 +685,36 @@ def main():
         # straight behind a policy kernel the actions are cache-resident instead: the same chain with a 16-batch pool
         best = None
         for q in (1, 2):
-            env.set_queue_mode(True, q)
+            env.set_queue_mode(True, q, ordering="host")
             wq, _ = time_steps(env, K, R, min(W, 50), pool[:16])
             if best is None or wq < best[0]:
                 best = (wq, q)
         out["actions_cache_resident"] = {"value": total_envs * steps_timed / best[0], "unit": "env-steps/s", "private_queues": best[1],
                                          "step_period_us": best[0] * 1e6 / steps_timed,
-                                         "frac": bpe * n / (best[0] / steps_timed) / 1e9 / HBM_PEAK_GBS,
-                                         "what": "16-batch action pool (16 MB) instead of the headline's %d batches (%.0f MB)" % (P, P * n * 16 / 1e6)}
-        env.set_queue_mode(True, queues)
-    if queue_mode == "private" and args.no_extras:
-        env.set_queue_mode(False)                          # nothing below steps this env again
-    elif queue_mode == "private":
-        # the same chain as ordinary HIP launches (what round 1 measured), for the difference the release fence makes
+                                         "frac": frac_of(best[0] * 1e6 / steps_timed),
+                                         "what": "16-batch action pool (%d MB) instead of the headline's %d batches (%.0f MB)"
+                                                 % (16 * n * 16 // 1000000, P, P * n * 16 / 1e6)}
+        env.set_queue_mode(True, queues, ordering="host")
+    if queue_mode == "private":
+        # the same chain as ordinary HIP launches: every kernel ends with the agent-scope release, i.e. every step's outputs are
+        # consumable by the next kernel on the stream -- the rate of a per-step `obs -> policy -> env.step` loop's env side
         env.set_queue_mode(False)
         wh, msh = time_steps(env, K, R, min(W, 50), pool, 1)
         out["hip_stream_mode"] = {"value": total_envs * steps_timed / wh, "unit": "env-steps/s", "step_period_us": wh * 1e6 / steps_timed,
-                                  "frac": bpe * n / (wh / steps_timed) / 1e9 / HBM_PEAK_GBS,
+                                  "frac": frac_of(wh * 1e6 / steps_timed), "read_frac": frac_of(wh * 1e6 / steps_timed, rbpe),
                                   "gpu_timeline_us_per_step": msh * 1e3 / steps_timed,
-                                  "what": "identical launches through hipLaunchKernel on the HIP stream (agent-scope release after every kernel)"}
+                                  "what": "identical launches through hipLaunchKernel on the HIP stream (agent-scope release after every "
+                                          "kernel: outputs consumable per step, in stream order)"}
     if not args.no_parity and rank == 0:
         out["parity"] = parity_vs_reference(qa, local_rank)
 
     if not args.no_extras:
-        # the same step with ONE launch per step (no groups): the per-kernel view
-        if groups > 1:
-            env.set_groups(1)
-            w1, ms1 = time_steps(env, K, R, min(W, 50), pool, 1)
-            out["single_launch_per_step"] = {"value": total_envs * steps_timed / w1, "unit": "env-steps/s",
-                                             "step_period_us": w1 * 1e6 / steps_timed,
-                                             "frac": bpe * n / (w1 / steps_timed) / 1e9 / HBM_PEAK_GBS,
-                                             "gpu_timeline_us_per_step": ms1 * 1e3 / steps_timed}
-        # fused roll-out leg: T steps per launch, state in registers (different algorithmic bytes: see DESIGN.md)
-        T = args.rollout_T
-        acts = pool[:T] if P >= T else env.random_actions(T)
-        reps = max(1, min(20, steps_timed // T))
-        env.rollout(acts)
-        barrier()
-        env.timer_start()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            o_, r_, d_, f_ = env.rollout(acts, want_flags=False)
-        ms = env.timer_stop()
-        torch.cuda.synchronize()
-        w2 = max_over_ranks(time.perf_counter() - t0)
-        b_roll = 16 + 48 + 4 + 1 + 320.0 / T
-        out["rollout_fused"] = {"value": total_envs * T * reps / w2, "unit": "env-steps/s", "T": T, "launches": reps,
-                                "bytes_per_env_step": b_roll,
-                                "hbm_frac": b_roll * n * T * reps / w2 / 1e9 / HBM_PEAK_GBS,
-                                "note": "qs_rollout: identical results to T qs_step calls; VALU-bound, not HBM-bound"}
-        del o_, r_, d_, f_
-        # rk4 integrator (the physically intended mode; same kernel, 4 df evaluations per drone)
-        other = "rk4" if args.integrator == "frozen" else "frozen"
-        env_o = make_env(other)
-        env_o.reset()
-        Ko = max(100, steps_timed // 4)
-        w3, ms3 = time_steps(env_o, Ko, 1, min(W, 50), pool)
-        out["other_integrator"] = {"integrator": other, "value": total_envs * Ko / w3, "unit": "env-steps/s",
-                                   "step_period_us": w3 * 1e6 / Ko}
-        env_o.close()
-        # the same step kernel where it is not latency-bound: 1 048 576 envs per GPU (168 MB of state, 16 waves per
-        # SIMD): shows the kernel's bandwidth ceiling beside the 65 536-env headline
-        if n < (1 << 20):
-            nb = 1 << 20
-            env_b = make_env(args.integrator, nb, rank * nb)
-            env_b.reset()
-            pool_b = env_b.random_actions(8, step0=0)
-            wb, msb = time_steps(env_b, 200, 1, 20, pool_b)
-            out["step_api_1M_envs"] = {"envs_per_gpu": nb, "value": nb * world * 200 / wb, "unit": "env-steps/s",
-                                       "step_period_us": wb * 1e6 / 200,
-                                       "hbm_frac": bpe * nb / (wb / 200) / 1e9 / HBM_PEAK_GBS}
-            env_b.close()
-            del pool_b
-        # policy in the loop: a = clip(MLP(obs)); env.step(a), T steps per launch, the shipped PPO2
-        # actor (weights fixture) on the matrix cores.  Needs nominal / rocRAND-initialised resets and no per-env params.
-        wpath = os.path.join(ROOT, "tests", "golden", "policy_best_model_v0.npz")
-        if args.randomise <= 1 and os.path.exists(wpath):
-            from quadsim_amd import MlpPolicy, fused_policy_rollout
-            pol = MlpPolicy.from_npz(wpath, device="cuda:%d" % local_rank)
-            Tp = 32
-            flop = 2 * (12 * 128 + 128 * 128 + 128 * 4)
-            for prec, key in (("f32", "policy_rollout_f32_mfma"), ("bf16x3", "policy_rollout_bf16x3_mfma")):
-                fused_policy_rollout(env, pol, Tp, want_actions=False, precision=prec)
-                barrier()
-                t0 = time.perf_counter()
-                for _ in range(4):
-                    fused_policy_rollout(env, pol, Tp, want_actions=False, precision=prec)
-                torch.cuda.synchronize()
-                w5 = max_over_ranks(time.perf_counter() - t0)
-                out[key] = {"value": total_envs * Tp * 4 / w5, "unit": "env-steps/s", "T": Tp,
-                            "mlp_tflops": total_envs * Tp * 4 * flop / w5 / 1e12}
-            out["policy_rollout_f32_mfma"]["roofline"] = {
-                "bound": "mfma", "peak": 157.3 * world, "unit": "TFLOP/s",
-                "achieved": out["policy_rollout_f32_mfma"]["mlp_tflops"],
-                "frac": out["policy_rollout_f32_mfma"]["mlp_tflops"] / (157.3 * world),
-                "note": "exact-f32 MFMA (v_mfma_f32_16x16x4_f32); 36 864 MLP flop per env-step"}
-            out["policy_rollout_bf16x3_mfma"]["note"] = "split-bf16 operands, 3 MFMAs per product, ~1e-5 action error (opt-in)"
-            # PPO2 data collection (Runner._run, rl_baselines/ppo2/ppo2.py:472-527): actor + critic + Gaussian sampling +
-            # neglogp + env.step for n_steps in one launch, then GAE + flatten + episode accounting
-            from quadsim_amd import ActorCriticPolicy, Runner
-            ac = ActorCriticPolicy.from_npz(wpath, device="cuda:%d" % local_rank)
-            flop_ac = 2 * (12 * 128 + 2 * 128 * 128 + 128 * 4 + 128)
-            for prec, key in (("f32", "ppo2_runner_f32_mfma"), ("bf16x3", "ppo2_runner_bf16x3_mfma")):
-                runner = Runner(env=env, model=ac, n_steps=Tp, gamma=0.99, lam=0.95, collect_ep_infos=False, precision=prec)
-                runner.run()
-                barrier()
-                t0 = time.perf_counter()
-                for _ in range(4):
-                    runner.run()
-                torch.cuda.synchronize()
-                w6 = max_over_ranks(time.perf_counter() - t0)
-                out[key] = {"value": total_envs * Tp * 4 / w6, "unit": "env-steps/s", "T": Tp,
-                            "mlp_tflops": total_envs * (Tp + 1) * 4 * flop_ac / w6 / 1e12}
-            out["ppo2_runner_f32_mfma"]["what"] = (
-                "Runner.run(): qs_runner_rollout (policy + value nets on exact-f32 MFMA, rocRAND Gaussian sampling, "
-                "neglogp, fused env.step) + qs_gae_flatten + qs_episode_stats + swap_and_flatten of obs / actions")
-            out["ppo2_runner_bf16x3_mfma"]["note"] = "the same with split-bf16 operands (qs_runner_rollout_fast), ~1e-5 error on means / values (opt-in)"
-        if distributed and args.backend == "nccl":
-            # BASELINE configs 4/5: RCCL all-gather of the roll-out slabs (obs, reward, done) once per T-step roll-out
-            from quadsim_amd.distributed import gather_slab
-            slab = env.rollout_slab(acts)
-            gathered = gather_slab(slab)
-            barrier()
-            t0 = time.perf_counter()
-            for _ in range(reps):
-                env.rollout_slab(acts, out=slab)
-                gather_slab(slab, out=gathered)
-            torch.cuda.synchronize()
-            w4 = max_over_ranks(time.perf_counter() - t0)
-            out["allgather"] = {"value": total_envs * T * reps / w4, "unit": "env-steps/s", "world_size": dist.get_world_size(),
-                                "backend": dist.get_backend(),
-                                "what": "qs_rollout_slab(T=%d) + ONE RCCL all_gather of the packed (obs, reward, done) slab "
-                                        "(%.1f MB per rank per roll-out)" % (T, T * n * 56 / 1e6)}
+        extras(args, out, env, pool, make_env, time_steps, verify_private_queue, barrier, max_over_ranks, queue_mode, queues,
+               dict(n=n, world=world, rank=rank, local_rank=local_rank, total_envs=total_envs, K=K, R=R, W=W, P=P, bpe=bpe, rbpe=rbpe,
+                    groups=groups, steps_timed=steps_timed, distributed=distributed))
 
-    if rank == 0 and not args.no_cpu_baseline and world == 1:
+    # the CPU legs run on rank 0 whatever the world size (they are CPU-only; the other ranks wait in the barrier below)
+    if rank == 0 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(kind, args.cpu_seconds)
         out["config1"] = config1_cpu()
     elif rank == 0:
@@ -672,6 +728,234 @@ def main():
     os.close(saved_stdout)
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def extras(args, out, env, pool, make_env, time_steps, verify_private_queue, barrier, max_over_ranks, queue_mode, queues, X):
+    """every leg beside the headline; each under its own name in the line"""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    n, world, rank, local_rank, total_envs = X["n"], X["world"], X["rank"], X["local_rank"], X["total_envs"]
+    K, R, W, P, bpe, rbpe, groups, steps_timed = X["K"], X["R"], X["W"], X["P"], X["bpe"], X["rbpe"], X["groups"], X["steps_timed"]
+    frac_of = lambda us, b=bpe, nn=n: b * nn / (us * 1e-6) / 1e9 / HBM_PEAK_GBS      # noqa: E731
+    # the same step with ONE launch per step (no groups): the per-kernel view
+    if groups > 1:
+        env.set_groups(1)
+        w1, ms1 = time_steps(env, K, R, min(W, 50), pool, 1)
+        out["single_launch_per_step"] = {"value": total_envs * steps_timed / w1, "unit": "env-steps/s",
+                                         "step_period_us": w1 * 1e6 / steps_timed, "frac": frac_of(w1 * 1e6 / steps_timed),
+                                         "gpu_timeline_us_per_step": ms1 * 1e3 / steps_timed}
+    # ---- roll-out through the step API with every step's outputs KEPT: T = 600 single-step launches per call (the reference's
+    #      n_steps, run_docking_ppo2.py:95), [T,N,...] output arrays; private queues stream-ordered: ONE GPU-side hand-shake with
+    #      the caller's stream and ONE release per call (qs_rollout_stepwise), no host synchronisation
+    Tr = 600 if n <= 131072 else 64
+    acts_r = env.random_actions(Tr, step0=0)
+    ro = {}
+    for mode in (("hip", "private_stream_ordered") if queue_mode == "private" else ("hip",)):
+        if mode == "hip":
+            env.set_queue_mode(False)
+        else:
+            env.set_queue_mode(True, queues, ordering="stream")
+            if env.queue_ordering != "stream":
+                continue
+        bufs = env.rollout(acts_r, stepwise=True)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            env.rollout(acts_r, stepwise=True, out=bufs)
+        torch.cuda.synchronize()
+        wr = max_over_ranks(time.perf_counter() - t0) / (3 * Tr)
+        ro[mode] = {"value": total_envs / wr, "unit": "env-steps/s", "step_period_us": wr * 1e6, "frac": frac_of(wr * 1e6),
+                    "read_frac": frac_of(wr * 1e6, rbpe)}
+        del bufs
+    ro["T"] = Tr
+    ro["what"] = ("qs_rollout_stepwise: T single-step launches per call, outputs of all T steps kept ([T,N,12] obs, [T,N] reward / done / "
+                  "flags, %.1f GB per call) and consumable in stream order when the call's hand-shake passes" % (Tr * n * 54 / 1e9))
+    out["rollout_stepwise"] = ro
+    del acts_r
+    env.set_queue_mode(False)
+    # ---- policy BETWEEN the steps (rl_baselines/ppo2/ppo2.py:472-499): obs -> the shipped MlpPolicy (three torch GEMMs +
+    #      activations on torch's stream) -> env.step, nothing pre-staged, no host synchronisation in either launch path
+    wpath = os.path.join(ROOT, "tests", "golden", "policy_best_model_v0.npz")
+    if os.path.exists(wpath):
+        from quadsim_amd import MlpPolicy
+        pol = MlpPolicy.from_npz(wpath, device="cuda:%d" % local_rank)
+        pb = {}
+        for mode in (("hip_stream", "private_stream_ordered") if queue_mode == "private" else ("hip_stream",)):
+            if mode == "hip_stream":
+                env.set_queue_mode(False)
+            else:
+                env.set_queue_mode(True, queues, ordering="stream")
+                if env.queue_ordering != "stream":
+                    continue
+            obs = env.reset()
+            for _ in range(30):
+                obs, _, _, _ = env.step(pol.predict(obs))
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(300):
+                obs, _, _, _ = env.step(pol.predict(obs))
+            torch.cuda.synchronize()
+            wp = max_over_ranks(time.perf_counter() - t0) / 300
+            pb[mode] = {"us_per_step": wp * 1e6, "value": total_envs / wp, "unit": "env-steps/s"}
+        # the env side alone, per-step consumable, from the raw C-ABI loop: HIP stream = `hip_stream_mode`; private queue with the
+        # per-step hand-shake (hipStreamWriteValue64 + hipStreamWaitValue64 per step are host-bound)
+        if "private_stream_ordered" in pb:
+            ws, _ = time_steps(env, 500, 1, 50, pool[:16])
+            pb["private_stream_ordered"]["env_step_alone_us"] = ws / 500 * 1e6
+        pb["what"] = ("VecDockingEnv.step(MlpPolicy.predict(obs)) per step, 300 steps; the policy is three torch GEMMs and dominates "
+                      "both; per-step consumable outputs cost a release per step in either path, so the private queue buys nothing "
+                      "here (DESIGN.md section 4a): use the HIP-stream mode for per-step loops, the fused qs_policy_rollout / "
+                      "qs_runner_rollout kernels for throughput")
+        out["policy_between_steps"] = pb
+        env.set_queue_mode(False)
+    # fused roll-out leg: T steps per launch, state in registers (different algorithmic bytes: see DESIGN.md)
+    T = args.rollout_T
+    acts = pool[:T] if P >= T else env.random_actions(T)
+    reps = max(1, min(20, steps_timed // T))
+    env.rollout(acts)
+    barrier()
+    env.timer_start()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        o_, r_, d_, f_ = env.rollout(acts, want_flags=False)
+    env.timer_stop()
+    torch.cuda.synchronize()
+    w2 = max_over_ranks(time.perf_counter() - t0)
+    b_roll = 16 + 48 + 4 + 1 + 320.0 / T
+    out["rollout_fused"] = {"value": total_envs * T * reps / w2, "unit": "env-steps/s", "T": T, "launches": reps,
+                            "bytes_per_env_step": b_roll,
+                            "hbm_frac": b_roll * n * T * reps / w2 / 1e9 / HBM_PEAK_GBS,
+                            "note": "qs_rollout: identical results to T qs_step calls; VALU-bound, not HBM-bound"}
+    del o_, r_, d_, f_
+    # rk4 integrator (the physically intended mode; same kernel, 4 df evaluations per drone)
+    other = "rk4" if args.integrator == "frozen" else "frozen"
+    env_o = make_env(other)
+    env_o.reset()
+    Ko = max(100, steps_timed // 4)
+    w3, ms3 = time_steps(env_o, Ko, 1, min(W, 50), pool)
+    out["other_integrator"] = {"integrator": other, "value": total_envs * Ko / w3, "unit": "env-steps/s",
+                               "step_period_us": w3 * 1e6 / Ko}
+    env_o.close()
+    # ---- the step API at 131 072 envs per GPU, on the driver's clock: docking-v0 (config 3's env) and the config-5 share
+    #      (docking-v2, per-env mass / inertia, 408 B): where the blueprint's 0.40 read-roofline target is (not) met
+    if n != 131072:
+        nb = 131072
+        legs = {}
+        for key, env_id, rnd, b_, rb_ in (("docking-v0", "docking-v0", 1, 392, 176), ("config5_share_docking-v2_mass_inertia", "docking-v2", 2, 408, 192)):
+            mk = lambda: make_env(args.integrator, nb, rank * nb, env_id, rnd)      # noqa: E731
+            e2 = mk()
+            e2.reset()
+            pool2 = e2.random_actions(min(128, P), step0=0)
+            qm, qq, note = _pick(args, e2, mk, pool2, time_steps, verify_private_queue, max_over_ranks, groups)
+            w5 = sorted(time_steps(e2, K, R, min(W, 50), pool2)[0] for _ in range(3))[1]
+            us = w5 * 1e6 / steps_timed
+            legs[key] = {"envs_per_gpu": nb, "value": nb * world / (us * 1e-6), "unit": "env-steps/s", "step_period_us": us,
+                         "bytes_per_env_step": b_, "frac": b_ * nb / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "read_frac": rb_ * nb / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                         "read_frac_target_met": bool(rb_ * nb / (us * 1e-6) / 1e9 / HBM_PEAK_GBS >= READ_TARGET),
+                         "queue_mode": qm, "private_queues": qq, "queue_note": note, "action_pool_batches": int(pool2.shape[0])}
+            e2.close()
+            del pool2
+        out["step_api_131072_envs"] = legs
+    # the same step kernel where it is not latency-bound: 1 048 576 envs per GPU (168 MB of state, 16 waves per
+    # SIMD): shows the kernel's bandwidth ceiling beside the headline
+    if n < (1 << 20):
+        nb = 1 << 20
+        env_b = make_env(args.integrator, nb, rank * nb)
+        env_b.reset()
+        pool_b = env_b.random_actions(8, step0=0)
+        wb, msb = time_steps(env_b, 200, 1, 20, pool_b)
+        out["step_api_1M_envs"] = {"envs_per_gpu": nb, "value": nb * world * 200 / wb, "unit": "env-steps/s",
+                                   "step_period_us": wb * 1e6 / 200,
+                                   "hbm_frac": bpe * nb / (wb / 200) / 1e9 / HBM_PEAK_GBS}
+        env_b.close()
+        del pool_b
+    # policy in the loop, fused (SURVEY.md 8f-1): a = clip(MLP(obs)); env.step(a), T steps per launch, the shipped PPO2
+    # actor (weights fixture) on the matrix cores.  Needs nominal / rocRAND-initialised resets and no per-env params.
+    if args.randomise <= 1 and os.path.exists(wpath):
+        from quadsim_amd import MlpPolicy, fused_policy_rollout
+        pol = MlpPolicy.from_npz(wpath, device="cuda:%d" % local_rank)
+        Tp = 32
+        flop = 2 * (12 * 128 + 128 * 128 + 128 * 4)
+        for prec, key in (("f32", "policy_rollout_f32_mfma"), ("bf16x3", "policy_rollout_bf16x3_mfma")):
+            fused_policy_rollout(env, pol, Tp, want_actions=False, precision=prec)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                fused_policy_rollout(env, pol, Tp, want_actions=False, precision=prec)
+            torch.cuda.synchronize()
+            w5 = max_over_ranks(time.perf_counter() - t0)
+            out[key] = {"value": total_envs * Tp * 4 / w5, "unit": "env-steps/s", "T": Tp,
+                        "mlp_tflops": total_envs * Tp * 4 * flop / w5 / 1e12}
+        out["policy_rollout_f32_mfma"]["roofline"] = {
+            "bound": "mfma", "peak": 157.3 * world, "unit": "TFLOP/s",
+            "achieved": out["policy_rollout_f32_mfma"]["mlp_tflops"],
+            "frac": out["policy_rollout_f32_mfma"]["mlp_tflops"] / (157.3 * world),
+            "note": "exact-f32 MFMA (v_mfma_f32_16x16x4_f32); 36 864 MLP flop per env-step"}
+        out["policy_rollout_bf16x3_mfma"]["note"] = "split-bf16 operands, 3 MFMAs per product, ~1e-5 action error (opt-in)"
+    if os.path.exists(wpath):
+        # PPO2 data collection (Runner._run, rl_baselines/ppo2/ppo2.py:472-527): actor + critic + Gaussian sampling +
+        # neglogp + env.step for n_steps in one launch, then GAE + flatten + episode accounting
+        from quadsim_amd import ActorCriticPolicy, Runner
+        Tp = 32
+        ac = ActorCriticPolicy.from_npz(wpath, device="cuda:%d" % local_rank)
+        flop_ac = 2 * (12 * 128 + 2 * 128 * 128 + 128 * 4 + 128)
+        for prec, key in (("f32", "ppo2_runner_f32_mfma"), ("bf16x3", "ppo2_runner_bf16x3_mfma")):
+            runner = Runner(env=env, model=ac, n_steps=Tp, gamma=0.99, lam=0.95, collect_ep_infos=False, precision=prec)
+            runner.run()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                runner.run()
+            torch.cuda.synchronize()
+            w6 = max_over_ranks(time.perf_counter() - t0)
+            out[key] = {"value": total_envs * Tp * 4 / w6, "unit": "env-steps/s", "T": Tp,
+                        "mlp_tflops": total_envs * (Tp + 1) * 4 * flop_ac / w6 / 1e12}
+        out["ppo2_runner_f32_mfma"]["what"] = (
+            "Runner.run(): qs_runner_rollout (policy + value nets on exact-f32 MFMA, rocRAND Gaussian sampling, "
+            "neglogp, fused env.step) + qs_gae_flatten + qs_episode_stats + swap_and_flatten of obs / actions")
+        out["ppo2_runner_bf16x3_mfma"]["note"] = "the same with split-bf16 operands (qs_runner_rollout_fast), ~1e-5 error on means / values (opt-in)"
+    if X["distributed"] and args.backend == "nccl":
+        # BASELINE configs 4/5: RCCL all-gather of the roll-out slabs (obs, reward, done) once per T-step roll-out
+        from quadsim_amd.distributed import gather_slab
+        slab = env.rollout_slab(acts)
+        gathered = gather_slab(slab)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            env.rollout_slab(acts, out=slab)
+            gather_slab(slab, out=gathered)
+        torch.cuda.synchronize()
+        w4 = max_over_ranks(time.perf_counter() - t0)
+        out["allgather"] = {"value": total_envs * T * reps / w4, "unit": "env-steps/s", "world_size": dist.get_world_size(),
+                            "backend": dist.get_backend(),
+                            "what": "qs_rollout_slab(T=%d) + ONE RCCL all_gather of the packed (obs, reward, done) slab "
+                                    "(%.1f MB per rank per roll-out)" % (T, T * n * 56 / 1e6)}
+
+
+def _pick(args, env, mk, pool, time_steps, verify_private_queue, max_over_ranks, groups):
+    """launch path for a side leg: as the headline's pick_launch_path (verified bit-identical per candidate, fastest on a probe)"""
+    if args.queue_mode == "hip" or groups > 1:
+        return "hip", 0, None
+    cand = [int(args.queues)] if args.queue_mode == "private" else [1, 2, 3]
+    best_t = time_steps(env, 300, 1, 50, pool)[0] if args.queue_mode == "auto" else float("inf")
+    notes, queues = ["HIP stream: %.2f us per step on the probe" % (best_t / 300 * 1e6)] if args.queue_mode == "auto" else [], 0
+    for q in cand:
+        ok, why = verify_private_queue(mk, pool, q)
+        if -max_over_ranks(-float(ok)) < 0.5:
+            notes.append("%d private queue(s) not used: %s" % (q, why if not ok else "another rank could not verify it"))
+            continue
+        env.set_queue_mode(True, q, ordering="host")
+        t = time_steps(env, 300, 1, 50, pool)[0]
+        notes.append("%d private queue(s): %.2f us per step on the probe" % (q, t / 300 * 1e6))
+        if t < best_t:
+            best_t, queues = t, q
+    if queues:
+        env.set_queue_mode(True, queues, ordering="host")
+    else:
+        env.set_queue_mode(False)
+    return ("private" if queues else "hip"), queues, "; ".join(notes)
 
 
 if __name__ == "__main__":

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define QS_VERSION 120 /* 0.1.2: + private-queue mode; 0.1.1: qs_step_ex, env groups, qs_gae_flatten, qs_episode_stats, ... */
+#define QS_VERSION 130 /* 0.1.3: + stream-ordered private queues (qs_set_queue_ordering); 0.1.2: + private-queue mode; 0.1.1: qs_step_ex, env groups, qs_gae_flatten, qs_episode_stats, ... */
 
 enum {
     QS_OK = 0,
@@ -145,7 +145,8 @@ int qs_step_ex(QsEnv *env, const float *actions, float *obs, float *reward, uint
  *     the calling thread only posts a launch record (a lone host thread issues ~0.35 launches / us, less than two
  *     groups consume).
  *   qs_group_range: [env_begin, env_end) of group g.   qs_group_stream: its hipStream_t (run that group's policy on
- *     it and no cross-stream ordering is needed at all);  qs_group_set_stream: use a caller-owned stream instead.
+ *     it and no cross-stream ordering is needed at all: qs_step_group / qs_step_groups return only after the launch is
+ *     ON that stream, launcher thread or not);  qs_group_set_stream: use a caller-owned stream instead.
  *   qs_step_group(env, g, ...): one step of group g on its stream; every pointer addresses the GROUP's rows
  *     (actions [n_g,4], obs [n_g,12], ... of envs env_begin..env_end-1).
  *   qs_step_groups(env, ...): one step of ALL groups, full-batch [N,...] pointers as qs_step_ex; one call, G launches.
@@ -174,20 +175,35 @@ int qs_groups_join(QsEnv *env);
  * its own; qs_step / qs_step_ex / qs_rollout_stepwise then write one packet per step (ordered behind the previous one,
  * acquire at agent scope, NO release) -- results bit-identical to the default mode.  Contract:
  *   - the handle's own calls stay ordered: any other entry point first drains the queue with a system-scope release
- *     (host wait), and the first step after such a call waits for the handle's stream;
- *   - what the CALLER has in flight on HIP streams is not ordered against the queue: the buffers passed to a step must
- *     be complete when it is called, and its outputs may be read after qs_sync() (or any other entry point): this is
- *     the mode for pre-staged actions / roll-outs; with a policy kernel between the steps use the default mode;
+ *     (host wait);
+ *   - ordering against the CALLER's work, QS_ORDER_STREAM (default wherever the device has stream memory operations,
+ *     hipDeviceAttributeCanUseStreamWaitValue): a step behaves like a launch on the handle's stream although it runs on
+ *     the private queue -- the call enqueues a write-value on the stream (inputs produced on that stream before the call
+ *     are complete when the step starts), the queue's packets wait for it, the last packet of the call releases at agent
+ *     scope and signals, and the call ends by enqueuing a wait-value on the stream (work enqueued on that stream after
+ *     the call sees the outputs).  No host synchronisation: `obs -> policy kernels -> qs_step` loops run exactly as in
+ *     the default mode (rl_baselines/ppo2/ppo2.py:472-499) -- but no faster: a per-step loop pays the release every
+ *     step, as a HIP launch does, plus the hand-shake; the mode pays off for qs_rollout_stepwise, which hand-shakes and
+ *     releases ONCE for its T steps.  Not capturable into a hipGraph; switching the handle's stream (qs_set_stream)
+ *     synchronises the old one.
+ *   - QS_ORDER_HOST (round 2's contract, qs_set_queue_ordering; the fallback without stream memory operations): no
+ *     hand-shake -- the buffers passed to a step must be complete when it is called, and its outputs may be read after
+ *     qs_sync() (or any other entry point);
  *   - every workgroup checks that it runs on the XCD that holds its tile (the hardware deals blocks to XCDs round-robin
- *     from a fixed start; HIP does not promise it): if that ever fails the workgroup touches nothing and the next
- *     synchronising call returns QS_ERR_HIP.
+ *     from a fixed start; HIP does not promise it): the owning XCD of a tile is kept in a word that is only accessed by
+ *     agent-scope atomics, so every XCD sees it; if the check ever fails the workgroup touches nothing and the next
+ *     synchronising call (qs_sync, qs_get_state, ...) returns QS_ERR_HIP.
  * mode = the number of private queues, 1..4: with more than one, the tiles are split into that many contiguous ranges and
  * every step writes one packet per queue -- the chains then overlap each other's kernel boundary (65 536 envs: 5.2 us per
  * step with one queue, 4.6 us with two; without the release there is no chip-wide write-back for them to collide on).
+ * qs_set_params / qs_set_init_state after qs_set_queue_mode are honoured (the step-kernel variant is re-resolved).
  * Docking envs, device buffers. */
 enum { QS_QUEUE_HIP_STREAM = 0, QS_QUEUE_PRIVATE = 1 /* 2, 3, 4: that many private queues */ };
+enum { QS_ORDER_HOST = 0, QS_ORDER_STREAM = 1 };
 int qs_set_queue_mode(QsEnv *env, int32_t mode);
 int qs_get_queue_mode(QsEnv *env, int32_t *mode);
+int qs_set_queue_ordering(QsEnv *env, int32_t ordering); /* QS_ORDER_*; QS_ERR_INVALID outside private-queue mode */
+int qs_get_queue_ordering(QsEnv *env, int32_t *ordering);
 
 /* T consecutive steps in ONE launch, env state held in registers (the loop body of the
  * trainer's Runner, rl_baselines/ppo2/ppo2.py:472-499, with the policy's actions pre-staged).

@@ -19,6 +19,7 @@ KIND_V0, KIND_V2, KIND_V1, KIND_HOVER = 0, 1, 2, 3
 INTEG_FROZEN, INTEG_RK4 = 0, 1
 IO_DEVICE, IO_HOST = 0, 1
 RANDOMISE_NONE, RANDOMISE_INIT, RANDOMISE_PARAMS = 0, 1, 2
+ORDER_HOST, ORDER_STREAM = 0, 1
 FLAG_DOCKED, FLAG_OVERLIMIT, FLAG_OVERTIME, FLAG_CHASER_LIMITED, FLAG_TARGET_LIMITED = 1, 2, 4, 8, 16
 
 EXPORTS = [
@@ -30,7 +31,7 @@ EXPORTS = [
     "qs_step_ex", "qs_set_groups", "qs_group_count", "qs_group_range", "qs_group_stream", "qs_group_set_stream",
     "qs_step_group", "qs_step_groups", "qs_groups_fork", "qs_groups_join",
     "qs_swap_and_flatten_u8", "qs_gae_flatten", "qs_episode_stats", "qs_set_rollout_layout",
-    "qs_set_queue_mode", "qs_get_queue_mode",
+    "qs_set_queue_mode", "qs_get_queue_mode", "qs_set_queue_ordering", "qs_get_queue_ordering",
 ]
 
 
@@ -155,6 +156,8 @@ def load():
         "qs_set_rollout_layout": [vp, i32],
         "qs_set_queue_mode": [vp, i32],
         "qs_get_queue_mode": [vp, C.POINTER(i32)],
+        "qs_set_queue_ordering": [vp, i32],
+        "qs_get_queue_ordering": [vp, C.POINTER(i32)],
     }
     for name, args in sig.items():
         fn = getattr(lib, name)

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <hsa/hsa.h>
 #include <hsa/hsa_ext_amd.h>
+#include <hsa/amd_hsa_signal.h>
 
 #include <elf.h>
 #include <fcntl.h>
@@ -53,16 +54,23 @@ using namespace qs;
 // 100 MHz real-time counter at its phase boundaries into a caller-provided buffer (qs_debug_set_stamps), keyed by
 // (step counter, tile) -- the in-kernel timeline of consecutive launches of the real chain.  Never in the product build.
 #ifdef QS_STAMP
-__device__ unsigned long long *g_qs_stamps = nullptr;
-__device__ unsigned long long g_qs_stamp_cap = 0;
+// The stamp buffer travels in StepArgs (not in a __device__ global): the private-queue launches run a second copy of the code
+// object, loaded through HSA, whose globals HIP's hipMemcpyToSymbol never reaches.
 // stamps stay in registers until the wave's last instruction: a store next to a barrier would be waited for by it
 #define QS_STAMP_DECL unsigned long long stamp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+// -DQS_STAMP=2 ("light"): only the first and the last stamps of a wave (start; stores drained) and no extra waits in between --
+// every s_memrealtime is a scalar-memory round trip, eight of them and the load-landed waits cost ~0.7 us per step, too much
+// for a timeline whose PERIOD is to be compared with the unstamped chain
+#if QS_STAMP + 0 >= 2
+#define QS_STAMP_AT(slot) ((void)((((slot) == 0) || ((slot) >= 6)) ? (stamp_[slot] = __builtin_amdgcn_s_memrealtime()) : 0ull))
+#else
 #define QS_STAMP_AT(slot) (stamp_[slot] = __builtin_amdgcn_s_memrealtime())
+#endif
 #define QS_STAMP_FLUSH()                                                                                        \
     do {                                                                                                        \
-        if (lane == 0 && g_qs_stamps) {                                                                         \
-            const unsigned long long ix_ = ((k0 % 64ull) * (unsigned long long)(A.tile_end) + (unsigned long long)tile) * 16ull + 8 * role; \
-            if (ix_ + 8 <= g_qs_stamp_cap) for (int j_ = 0; j_ < 8; ++j_) g_qs_stamps[ix_ + j_] = stamp_[j_];    \
+        if (lane == 0 && A.stamps) {                                                                            \
+            const unsigned long long ix_ = ((k0 % 64ull) * (unsigned long long)(A.stamp_tiles) + (unsigned long long)tile) * 16ull + 8 * role; \
+            if (ix_ + 8 <= A.stamp_cap) for (int j_ = 0; j_ < 8; ++j_) A.stamps[ix_ + j_] = stamp_[j_];          \
         }                                                                                                       \
     } while (0)
 // runner kernels: phase durations summed over the T steps of one launch, [tile][role][8] words
@@ -73,9 +81,9 @@ __device__ unsigned long long g_qs_stamp_cap = 0;
     do {                                                                                                        \
         ph_[6] = __builtin_amdgcn_s_memtime() - ph_c0_;          /* shader clocks ... */                         \
         ph_[7] = __builtin_amdgcn_s_memrealtime() - ph_r0_;      /* ... per 10 ns ticks = the clock frequency */ \
-        if (lane == 0 && g_qs_stamps) {                                                                         \
+        if (lane == 0 && A.stamps) {                                                                            \
             const unsigned long long ix_ = (unsigned long long)tile * 16ull + 8 * (role_);                      \
-            if (ix_ + 8 <= g_qs_stamp_cap) for (int j_ = 0; j_ < 8; ++j_) g_qs_stamps[ix_ + j_] = ph_[j_];       \
+            if (ix_ + 8 <= A.stamp_cap) for (int j_ = 0; j_ < 8; ++j_) A.stamps[ix_ + j_] = ph_[j_];             \
         }                                                                                                       \
     } while (0)
 #else
@@ -100,6 +108,51 @@ __device__ unsigned long long g_qs_stamp_cap = 0;
 #endif
 
 namespace {
+
+constexpr int kTileLanes = 64;   // == qs::kTile (one wavefront)
+
+// Write-through (`sc1`) stores for the OUTPUTS of a step launched without the end-of-kernel release (StepArgs::out_wt): such a
+// launch leaves plain / `nt` stores dirty in the stepping XCD's L2, which no other queue's kernel reads; `sc1` bytes are in
+// memory once the store is acknowledged, and s_endpgm waits for every outstanding store of the wave.  The state rows keep `nt`
+// (they are meant to stay in that L2).  16-B form by inline asm (there is no 16-B atomic store); scalars by agent-scope atomics.
+typedef float qs_f4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st_wt(qs_f4 *p, qs_f4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+__device__ __forceinline__ void st_wt(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_wt(uint8_t *p, uint8_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T> __device__ __forceinline__ void st_out(T *p, T v, int wt)
+{
+    if (wt) st_wt(p, v);
+    else QS_SO(p, v);
+}
+
+// reward / done / flags of ONE WHOLE TILE, write-through, as 16 B per lane.  A wave's scalar `sc1` store is one fabric write per
+// LANE (MI355X_MICROARCH.md: dword ~6x, byte ~12x the time per byte of a 16-B store): the three narrow rows of a tile are 192
+// such writes -- 2 us per step at 65 536 envs, measured -- against 24 when the rows pass through a wave-private LDS block
+// first: lanes 0..15 then carry the 64 rewards, lanes 16..19 the 64 done bytes, lanes 20..23 the 64 flag bytes.
+struct alignas(16) TailStage {
+    float rew[kTileLanes];
+    uint8_t done[kTileLanes], flags[kTileLanes];
+};
+__device__ __forceinline__ bool tail_rows_aligned(const float *rew_row, const uint8_t *done_row, const uint8_t *flags_row)
+{
+    return (((uintptr_t)rew_row | (uintptr_t)done_row | (uintptr_t)flags_row) & 15u) == 0;      // a null flags row is aligned
+}
+__device__ __forceinline__ void store_tail_wt(TailStage &S, int lane, float *rew_row, uint8_t *done_row, uint8_t *flags_row, float r,
+                                              uint8_t d, uint8_t f)
+{
+    S.rew[lane] = r; S.done[lane] = d; S.flags[lane] = f;
+    // same wave on both sides: LDS operations of a wave complete in order; keep the compiler from moving the reads up
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    const qs_f4 *src = nullptr;
+    qs_f4 *dst = nullptr;
+    if (lane < 16) { src = reinterpret_cast<const qs_f4 *>(S.rew) + lane; dst = reinterpret_cast<qs_f4 *>(rew_row) + lane; }
+    else if (lane < 20) { src = reinterpret_cast<const qs_f4 *>(S.done) + (lane - 16); dst = reinterpret_cast<qs_f4 *>(done_row) + (lane - 16); }
+    else if (lane < 24 && flags_row) { src = reinterpret_cast<const qs_f4 *>(S.flags) + (lane - 20); dst = reinterpret_cast<qs_f4 *>(flags_row) + (lane - 20); }
+    if (dst) st_wt(dst, *src);
+    __builtin_amdgcn_wave_barrier();               // the next step's writes stay behind these reads
+}
 
 #ifndef QS_BLOCK
 #define QS_BLOCK 256
@@ -137,8 +190,16 @@ struct StepArgs {
     const float *init;     // stored per-env initial states: [N][26] (docking: chaser, target) / [N][13] (hovering)
     // private-queue launches (qs_set_queue_mode): the launch carries no release fence, so a tile's state stays dirty in the L2 of
     // the XCD that stepped it; `owner` [tiles] records that XCD and every workgroup checks that it runs where its tile lives
-    unsigned char *owner;  // nullptr: ordinary (fenced) launch, no check
+    unsigned *owner;       // nullptr: ordinary (fenced) launch, no check.  One 32-bit word per tile, 0xffffffff = unowned;
+                           // written and read with agent-scope atomics ONLY: like the state it guards, a plainly stored owner
+                           // would stay dirty in the writing XCD's L2 and a misplaced workgroup would never see it
     unsigned *err;         // device word: bit 0 set when a workgroup found its tile owned by another XCD (it then touches nothing)
+    int out_wt;            // != 0: obs / reward / done / flags / terminal rows are stored write-through (`sc1`): a launch without the
+                           // end-of-kernel release leaves plain and `nt` stores dirty in the XCD's L2, where no other queue's kernel
+                           // would find them; write-through outputs are in memory when the packet's completion signal fires
+    int dbg_shift;         // diagnostic (tests): workgroup b steps tile (b + dbg_shift) % tiles of its launch, i.e. on ANOTHER XCD
+    unsigned long long *stamps;        // QS_STAMP builds: in-kernel timeline buffer (qs_debug_set_stamps), else nullptr
+    unsigned long long stamp_cap, stamp_tiles;
 };
 
 __device__ __forceinline__ void load_env(const float *__restrict__ st, int64_t tile, int lane, Env &e)
@@ -189,13 +250,12 @@ __device__ __forceinline__ void store_par(float *__restrict__ par, int64_t tile,
     b[0] = P.m; b[kTile] = P.Ixx; b[2 * kTile] = P.Iyy; b[3 * kTile] = P.Izz;
 }
 
-__device__ __forceinline__ void store_obs(float *__restrict__ obs, int64_t env, const float o[12])
+__device__ __forceinline__ void store_obs(float *__restrict__ obs, int64_t env, const float o[12], int wt = 0)
 {
-    typedef float f4 __attribute__((ext_vector_type(4)));
-    f4 *p = reinterpret_cast<f4 *>(obs + env * 12);
-    QS_SO(&p[0], (f4{o[0], o[1], o[2], o[3]}));
-    QS_SO(&p[1], (f4{o[4], o[5], o[6], o[7]}));
-    QS_SO(&p[2], (f4{o[8], o[9], o[10], o[11]}));
+    qs_f4 *p = reinterpret_cast<qs_f4 *>(obs + env * 12);
+    st_out(&p[0], (qs_f4{o[0], o[1], o[2], o[3]}), wt);
+    st_out(&p[1], (qs_f4{o[4], o[5], o[6], o[7]}), wt);
+    st_out(&p[2], (qs_f4{o[8], o[9], o[10], o[11]}), wt);
 }
 
 // plain (cached) flavour: rows that are completed by LATER stores of the same lane (the env-major roll-out arrays, where a
@@ -222,29 +282,52 @@ __device__ __forceinline__ void step_counter_end(const StepArgs &A, int64_t tile
 // private-queue launches only: true when this wave must not touch its tile (the tile's latest state is in another XCD's L2).
 // Blocks are dealt to the XCDs round-robin from a start that is constant for a queue (measured: tools/xcc_map.hip), so this
 // never fires; it turns a change of that hardware behaviour into a loud error instead of stale state.
-// the same check for a caller that requested A.owner[tile] earlier (no load latency on its critical path)
+// The owner word is requested with an agent-scope atomic load (`sc1`: never served from a stale line of this XCD's L2 or this
+// CU's L1) and claimed with an agent-scope compare-and-swap executed at the memory side: every XCD sees the same word.
+constexpr unsigned kUnowned = 0xffffffffu;
+__device__ __forceinline__ unsigned chain_owner_request(const StepArgs &A, int64_t tile)
+{
+    return A.owner ? __hip_atomic_load(&A.owner[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kUnowned;
+}
+
+// the check for a caller that requested the owner word earlier (no load latency on its critical path)
 __device__ __forceinline__ bool chain_owner_mismatch(const StepArgs &A, int64_t tile, int lane, unsigned own)
 {
     const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;   // HW_REG_XCC_ID
-    if (own != 0xffu && own != xcc) {
-        if (lane == 0) atomicOr(A.err, 1u);
+    if (own == kUnowned) {
+        // first private step of this tile since the handle's last HIP-side call: claim it (both role waves may try; the
+        // second one finds its own XCD).  A claim lost to ANOTHER XCD is a misplacement like any other.
+        unsigned seen = kUnowned;
+        if (lane == 0) {
+            unsigned expect = kUnowned;
+            __hip_atomic_compare_exchange_strong(&A.owner[tile], &expect, xcc, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            seen = expect;
+        }
+        own = __builtin_amdgcn_readfirstlane(seen);
+        if (own == kUnowned) return false;
+    }
+    if (own != xcc) {
+        if (lane == 0) __hip_atomic_fetch_or(A.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return true;
     }
-    if (lane == 0 && own == 0xffu) A.owner[tile] = (unsigned char)xcc;
     return false;
 }
 
 __device__ __forceinline__ bool chain_tile_misplaced(const StepArgs &A, int64_t tile, int lane)
 {
     if (!A.owner) return false;
-    const unsigned xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) & 15u;   // HW_REG_XCC_ID
-    const unsigned own = A.owner[tile];
-    if (own != 0xffu && own != xcc) {
-        if (lane == 0) atomicOr(A.err, 1u);
-        return true;
+    return chain_owner_mismatch(A, tile, lane, chain_owner_request(A, tile));
+}
+
+// tile of workgroup-local index b (0 <= b < the launch's tile count); dbg_shift != 0 only in the placement-guard test
+__device__ __forceinline__ int64_t launch_tile(const StepArgs &A, int64_t b)
+{
+    if (A.dbg_shift) {
+        const int64_t nt = A.tile_end - A.tile0;
+        b += A.dbg_shift;
+        if (b >= nt) b -= nt;
     }
-    if (lane == 0 && own == 0xffu) A.owner[tile] = (unsigned char)xcc;
-    return false;
+    return A.tile0 + b;
 }
 
 template <bool PARAMS, int RMODE>
@@ -267,11 +350,16 @@ __device__ __forceinline__ void maybe_reset(Env &e, Par &P, const StepArgs &A, i
 {
     done = (flags & (FLAG_OVERLIMIT | FLAG_OVERTIME)) != 0;
     if (done && A.auto_reset) {
-        if (write_term && A.term_obs) store_obs(A.term_obs, env - A.io_env0, obs);
+        if (write_term && A.term_obs) store_obs(A.term_obs, env - A.io_env0, obs, A.out_wt);
         if (write_term && A.term_state) {
             float *ts = A.term_state + (env - A.io_env0) * 26;
+            if (A.out_wt) {
 #pragma unroll
-            for (int i = 0; i < 13; ++i) { ts[i] = e.sc[i]; ts[13 + i] = e.st[i]; }
+                for (int i = 0; i < 13; ++i) { st_wt(&ts[i], e.sc[i]); st_wt(&ts[13 + i], e.st[i]); }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 13; ++i) { ts[i] = e.sc[i]; ts[13 + i] = e.st[i]; }
+            }
         }
         if (RMODE == 0) {
             // nominal states are constants: no need to re-derive their observation per lane
@@ -306,10 +394,13 @@ __device__ __forceinline__ void maybe_reset(Env &e, Par &P, const StepArgs &A, i
 template <int INTEG, bool PARAMS, int RMODE>
 __global__ __launch_bounds__(kBlock) void k_env(StepArgs A)
 {
+    __shared__ TailStage s_tail[kBlock / kTile];
     const int lane = threadIdx.x & (kTile - 1);
-    const int64_t tile = A.tile0 + (int64_t)blockIdx.x * (kBlock / kTile) + (threadIdx.x >> 6);
+    const int64_t wg_tile = (int64_t)blockIdx.x * (kBlock / kTile) + (threadIdx.x >> 6);
+    if (wg_tile >= A.tile_end - A.tile0) return;
+    const int64_t tile = launch_tile(A, wg_tile);
     const int64_t env = tile * kTile + lane;
-    if (tile >= A.tile_end || env >= A.n) return;
+    if (env >= A.n) return;
     if (chain_tile_misplaced(A, tile, lane)) return;
     const int64_t io = env - A.io_env0;          // row of this env in the I/O arrays
     QS_ASSERT(io >= 0 && io < A.io_n);
@@ -345,11 +436,17 @@ __global__ __launch_bounds__(kBlock) void k_env(StepArgs A)
             for (int i = 0; i < 6; ++i) row[i] = make_float2(obs[2 * i], obs[2 * i + 1]);
             row[6] = make_float2(reward, done ? 1.0f : 0.0f);
         } else {
-            store_obs(A.obs, o, obs);
-            QS_SO(&A.reward[o], reward);
-            QS_SO(&A.done[o], (uint8_t)(done ? 1 : 0));
+            store_obs(A.obs, o, obs, A.out_wt);
+            float *rr = A.reward + (o - lane);
+            uint8_t *dr = A.done + (o - lane), *fr = A.flags ? A.flags + (o - lane) : nullptr;
+            if (A.out_wt && tile * kTile + kTile <= A.n && tail_rows_aligned(rr, dr, fr)) {
+                store_tail_wt(s_tail[threadIdx.x >> 6], lane, rr, dr, fr, reward, (uint8_t)(done ? 1 : 0), (uint8_t)flags);
+                continue;
+            }
+            st_out(&A.reward[o], reward, A.out_wt);
+            st_out(&A.done[o], (uint8_t)(done ? 1 : 0), A.out_wt);
         }
-        if (A.flags) QS_SO(&A.flags[o], (uint8_t)flags);
+        if (A.flags) st_out(&A.flags[o], (uint8_t)flags, A.out_wt);
     }
     store_env(A.st, tile, lane, e);
     if (PARAMS && RMODE == 2) store_par(A.par, tile, lane, P);
@@ -369,16 +466,17 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
     __shared__ float s_tgt[13][kTile];
     __shared__ uint4 s_phx[2][2][kTile];          // [step parity][block]: the chaser wave reads step t's words while t+1's are drawn
     __shared__ unsigned char s_done[kTile], s_limt[kTile];
+    __shared__ TailStage s_tail;
     const int lane = threadIdx.x & (kTile - 1);
     const int role = threadIdx.x >> 6;
-    const int64_t tile = A.tile0 + blockIdx.x;   // grid = the tiles of this launch's env group
+    const int64_t tile = launch_tile(A, blockIdx.x);   // grid = the tiles of this launch's env group
     const int64_t env = tile * kTile + lane;
     bool active = env < A.n;                     // idle lanes of the tail tile compute on zeros and store nothing
     const int64_t io = env - A.io_env0;          // row of this env in the I/O arrays
     QS_ASSERT(tile < A.tile_end && (!active || (io >= 0 && io < A.io_n)));
     // private-queue launches: the tile's owning XCD is requested here and examined only after the first compute phase (below),
     // so that the check costs no memory latency; a misplaced workgroup computes on whatever it loaded and stores nothing
-    const unsigned owner_xcc = A.owner ? A.owner[tile] : 0xffu;
+    const unsigned owner_xcc = chain_owner_request(A, tile);
     const uint64_t k0 = step_counter_begin(A, tile);
     QS_STAMP_DECL;
     QS_STAMP_AT(0);
@@ -401,7 +499,7 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
         // control, quadrotor.py:126-144) is done; its miss latency hides under drone_advance
         float4 av_next = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
         if (A.actions && active) av_next = reinterpret_cast<const float4 *>(A.actions)[io];
-#ifdef QS_STAMP
+#if defined(QS_STAMP) && QS_STAMP + 0 < 2
         asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
 #endif
         QS_STAMP_AT(1);
@@ -442,11 +540,16 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
             __syncthreads();                                              // #2: reset flags out, this step's Philox words in
             QS_STAMP_AT(5);
             if (rs) {
-                if (A.term_obs && active) store_obs(A.term_obs, io, obs);
+                if (A.term_obs && active) store_obs(A.term_obs, io, obs, A.out_wt);
                 if (A.term_state && active) {
                     float *ts = A.term_state + io * 26;
+                    if (A.out_wt) {
 #pragma unroll
-                    for (int i = 0; i < 13; ++i) ts[i] = sc[i];
+                        for (int i = 0; i < 13; ++i) st_wt(&ts[i], sc[i]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 13; ++i) ts[i] = sc[i];
+                    }
                 }
                 float ic[13], it[13];
                 if (RMODE == 0) {
@@ -480,11 +583,17 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
                     for (int i = 0; i < 6; ++i) row[i] = make_float2(obs[2 * i], obs[2 * i + 1]);
                     row[6] = make_float2(reward, done ? 1.0f : 0.0f);
                 } else {
-                    store_obs(A.obs, o, obs);
-                    QS_SO(&A.reward[o], reward);
-                    QS_SO(&A.done[o], (uint8_t)(done ? 1 : 0));
+                    store_obs(A.obs, o, obs, A.out_wt);
+                    float *rr = A.reward + (o - lane);
+                    uint8_t *dr = A.done + (o - lane), *fr = A.flags ? A.flags + (o - lane) : nullptr;
+                    if (A.out_wt && tile * kTile + kTile <= A.n && tail_rows_aligned(rr, dr, fr)) {
+                        store_tail_wt(s_tail, lane, rr, dr, fr, reward, (uint8_t)(done ? 1 : 0), (uint8_t)flags);
+                        continue;
+                    }
+                    st_out(&A.reward[o], reward, A.out_wt);
+                    st_out(&A.done[o], (uint8_t)(done ? 1 : 0), A.out_wt);
                 }
-                if (A.flags) QS_SO(&A.flags[o], (uint8_t)flags);
+                if (A.flags) st_out(&A.flags[o], (uint8_t)flags, A.out_wt);
             }
         }
         if (active) {
@@ -514,7 +623,7 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
         const float vdes[3] = {A.C.vdes_x, 0.0f, 0.0f};
         const float dv[3] = {0.0f, 0.0f, 0.0f};
         if (A.T == 1) __builtin_amdgcn_s_setprio(3);   // single step: the chaser wave waits at #1 for this wave's step + draw
-#ifdef QS_STAMP
+#if defined(QS_STAMP) && QS_STAMP + 0 < 2
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         QS_STAMP_AT(1);
@@ -548,8 +657,13 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
             if (s_done[lane]) {
                 if (A.term_state && active) {
                     float *ts = A.term_state + io * 26 + 13;
+                    if (A.out_wt) {
 #pragma unroll
-                    for (int i = 0; i < 13; ++i) ts[i] = st[i];
+                        for (int i = 0; i < 13; ++i) st_wt(&ts[i], st[i]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 13; ++i) ts[i] = st[i];
+                    }
                 }
                 float ic[13], it[13];
                 if (RMODE == 3) {
@@ -1400,6 +1514,11 @@ inline unsigned grid_flat(int64_t n) { return (unsigned)((n + kBlock - 1) / kBlo
 
 }  // namespace
 
+#ifdef QS_STAMP
+static unsigned long long *g_host_stamps = nullptr;     // qs_debug_set_stamps: handed to every launch through StepArgs
+static unsigned long long g_host_stamp_cap = 0;
+#endif
+
 struct QsEnv {
     QsConfig cfg;
     int64_t n = 0, tiles = 0;
@@ -1459,6 +1578,9 @@ StepArgs make_args(const QsEnv *e)
     A.randomise = e->cfg.randomise;
 
     for (int i = 0; i < 12; ++i) A.nominal_obs[i] = e->nominal_obs[i];
+#ifdef QS_STAMP
+    A.stamps = g_host_stamps; A.stamp_cap = g_host_stamp_cap; A.stamp_tiles = (unsigned long long)e->tiles;
+#endif
     return A;
 }
 
@@ -1640,6 +1762,14 @@ int group_post(QsGroup *g, const QsGroup::Req &r)
     return QS_OK;
 }
 
+// every record posted to group g has been issued to its stream
+void group_wait_issued(QsGroup *g)
+{
+    if (!g->threaded) return;
+    const uint64_t h = g->head.load(std::memory_order_relaxed);
+    while (g->tail.load(std::memory_order_acquire) != h) __builtin_ia32_pause();
+}
+
 // every posted record has been issued to its stream
 int groups_drain(QsEnv *e)
 {
@@ -1717,10 +1847,20 @@ void groups_destroy(QsEnv *e)
 //     header = KERNEL_DISPATCH | BARRIER (ordered behind the previous packet) | ACQUIRE agent (fresh kernargs / actions;
 //              0.16 us, does not touch dirty lines) | RELEASE none.
 // The handle therefore owns an HSA queue, loads its own copy of the library's code object into it, and writes one packet per
-// qs_step.  Everything else stays on HIP: any other entry point first DRAINS the queue with a release packet (host wait), and
-// the first step after HIP-side work waits for the handle's stream.  What the caller has in flight on HIP streams is not
-// ordered against the queue: inputs must be complete when qs_step is called, outputs are valid after qs_sync (pre-staged
-// actions, roll-outs; with a policy between the steps use the default mode).
+// qs_step.  Everything else stays on HIP: any other entry point first DRAINS the queue with a release packet (host wait).
+//
+// Ordering against the CALLER's work (the handle's stream S), round 3 -- QS_ORDER_STREAM, the default where the device has
+// stream memory operations: a step behaves like a launch on S although it runs elsewhere.  Per submission (one qs_step, or the
+// T steps of qs_rollout_stepwise):
+//     S:      hipStreamWriteValue64(fwd, n)              -- executes when everything enqueued on S so far has finished
+//     queue:  barrier-value packet (fwd >= n) | step packet(s), the last one with a completion signal `rev`
+//     S:      hipStreamWaitValue64(rev == V0 - n)        -- whatever is enqueued on S afterwards runs after the step(s)
+// and that last packet carries an agent-scope RELEASE, so that the outputs of all T steps are in memory -- not dirty in one XCD's
+// L2 -- when `rev` fires (the state lines are written back with them and stay valid in their L2).  No host synchronisation
+// anywhere.  A per-step loop (T = 1) thereby pays what a HIP launch pays -- per-step consumable outputs ARE the write-back:
+// write-through output stores instead of the release were measured no faster (the kernel then ends when memory, not the L2,
+// acknowledges its stores) -- plus the hand-shake; a T-step roll-out pays both once.  QS_ORDER_HOST is round 2's contract:
+// inputs complete at the call, outputs valid after qs_sync (no hand-shake packets).
 struct QsChainLane {                  // one private queue and the contiguous tile range it steps
     hsa_queue_t *queue = nullptr;
     char *kernargs = nullptr;
@@ -1728,6 +1868,11 @@ struct QsChainLane {                  // one private queue and the contiguous ti
     uint64_t issued = 0;              // step packets written so far
     int64_t tile0 = 0, tile_end = 0;
     hsa_signal_t done{};
+    // QS_ORDER_STREAM: completion signal of this lane's submissions.  Allocated by HIP as "signal memory" (the only memory
+    // hipStreamWaitValue64 accepts); HIP hands out the address of the signal's VALUE, the handle is the amd_signal_t around it.
+    void *rev_ptr = nullptr;
+    hsa_signal_t rev{};
+    int64_t rev_value = 0;            // value of `rev` once every submission so far has completed (counts DOWN: AQL decrements)
 };
 
 struct QsChain {
@@ -1740,14 +1885,22 @@ struct QsChain {
     bool have_exe = false, have_reader = false;
     std::vector<char> image;          // the gfx950 code object (kept alive for the executable)
     uint64_t kernel_object = 0;
+    int v_integ = -1, v_params = -1, v_rmode = -1, v_split = -1;   // the instantiation kernel_object belongs to
     uint32_t kernarg_size = 0, group_size = 0, private_size = 0;
     unsigned block = 0;
     size_t stride = 0, slots = 0;
-    unsigned char *d_owner = nullptr; // [tiles]
+    unsigned *d_owner = nullptr;      // [tiles] 32-bit words, agent-scope atomics only
     unsigned *d_err = nullptr;
     bool kernargs_on_device = false;  // kernarg ring in BAR-mapped device memory (else: host memory, correct but slow)
     bool dirty = false;               // packets enqueued since the last drain
     bool hip_dirty = true;            // the handle did HIP-side work since the last packet
+    // QS_ORDER_STREAM
+    bool stream_ordered = false;
+    void *fwd_ptr = nullptr;          // value word of the forward signal (HIP signal memory)
+    hsa_signal_t fwd{};
+    uint64_t fwd_seq = 0;             // submissions so far
+    int dbg_shift = 0;                // one-shot: the next step packet runs with StepArgs::dbg_shift (placement-guard test)
+    bool out_wt = false;              // A/B knob QS_CHAIN_OUT_WT=1: write-through outputs instead of the release on the publishing packet
 };
 
 namespace {
@@ -1761,6 +1914,8 @@ namespace {
             return fail(QS_ERR_HIP, "%s failed: %s", #expr, m_ ? m_ : "unknown HSA status");           \
         }                                                                                               \
     } while (0)
+
+constexpr int64_t kRevStart = (int64_t)1 << 40;
 
 struct AgentPick {
     uint32_t want_bdf, want_domain;
@@ -1872,17 +2027,90 @@ void chain_close(QsEnv *e)
 {
     QsChain *c = e->chain;
     if (!c) return;
+    // nothing may be left waiting on a hand-shake value that will never come
+    if (c->fwd.handle) hsa_signal_store_screlease(c->fwd, INT64_MAX);
     for (QsChainLane &L : c->lanes) {
         if (L.queue) hsa_queue_destroy(L.queue);
         if (L.kernargs) hsa_amd_memory_pool_free(L.kernargs);
         if (L.done.handle) hsa_signal_destroy(L.done);
+        if (L.rev_ptr) (void)hipFree(L.rev_ptr);
     }
+    if (c->fwd_ptr) (void)hipFree(c->fwd_ptr);
     if (c->have_exe) hsa_executable_destroy(c->exe);
     if (c->have_reader) hsa_code_object_reader_destroy(c->reader);
     if (c->d_owner) (void)hipFree(c->d_owner);
     if (c->d_err) (void)hipFree(c->d_err);
     delete c;
     e->chain = nullptr;
+}
+
+// the step-kernel instantiation launch_env_on would pick for the handle AS IT IS NOW (qs_set_params / qs_set_init_state after
+// qs_set_queue_mode change it): (re-)resolved against the loaded executable whenever it differs from the one in use
+int chain_resolve_kernel(QsEnv *e)
+{
+    QsChain *c = e->chain;
+    const int integ = e->cfg.integrator == QS_INTEG_FROZEN ? 0 : 1;
+    const int rmode = e->init ? 3 : e->cfg.randomise;
+    const int params = (rmode == 2 || e->per_env_params) ? 1 : 0;
+    static const int forced = getenv("QS_SPLIT") ? atoi(getenv("QS_SPLIT")) : -1;
+    const int split = (forced >= 0 ? forced != 0 : e->n <= kSplitMaxEnvs) ? 1 : 0;
+    if (c->kernel_object && integ == c->v_integ && rmode == c->v_rmode && params == c->v_params && split == c->v_split) return QS_OK;
+    char sym[160];
+    snprintf(sym, sizeof sym, split ? "_ZN12_GLOBAL__N_111k_env_splitILi%dELb%dELi%dEEEvNS_8StepArgsE.kd"
+                                    : "_ZN12_GLOBAL__N_15k_envILi%dELb%dELi%dEEEvNS_8StepArgsE.kd", integ, params, rmode);
+    hsa_executable_symbol_t ks;
+    uint64_t ko = 0;
+    uint32_t ka = 0, gs = 0, ps = 0;
+    HSA_TRY(hsa_executable_get_symbol_by_name(c->exe, sym, &c->gpu, &ks));
+    HSA_TRY(hsa_executable_symbol_get_info(ks, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &ko));
+    HSA_TRY(hsa_executable_symbol_get_info(ks, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &ka));
+    HSA_TRY(hsa_executable_symbol_get_info(ks, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &gs));
+    HSA_TRY(hsa_executable_symbol_get_info(ks, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &ps));
+    if (ka < sizeof(StepArgs)) return fail(QS_ERR_HIP, "qs_set_queue_mode: kernel argument block is %u B, StepArgs %zu B", ka, sizeof(StepArgs));
+    if (c->stride && (((size_t)ka + 255) & ~size_t(255)) > c->stride)
+        return fail(QS_ERR_HIP, "queue mode: kernel argument block of %s (%u B) exceeds the ring's slot size", sym, ka);
+    c->kernel_object = ko; c->kernarg_size = ka; c->group_size = gs; c->private_size = ps;
+    c->block = split ? 2 * kTile : kBlock;
+    c->v_integ = integ; c->v_rmode = rmode; c->v_params = params; c->v_split = split;
+    return QS_OK;
+}
+
+// HIP "signal memory": an HSA signal created by HIP, of which it hands out the address of the value word.  The handle our
+// own AQL packets need is the amd_signal_t around that word (amd_hsa_signal.h: value at offset 8, 64-byte aligned).
+int chain_alloc_hip_signal(void **value_ptr, hsa_signal_t *handle, int64_t initial)
+{
+    HIP_TRY(hipExtMallocWithFlags(value_ptr, 8, hipMallocSignalMemory));
+    const uintptr_t h = (uintptr_t)*value_ptr - offsetof(amd_signal_t, value);
+    if (h & (AMD_SIGNAL_ALIGN_BYTES - 1)) return fail(QS_ERR_HIP, "queue mode: HIP signal memory is not the value word of an amd_signal_t");
+    handle->handle = (uint64_t)h;
+    if (((amd_signal_t *)h)->kind != AMD_SIGNAL_KIND_USER) return fail(QS_ERR_HIP, "queue mode: HIP signal memory is not a user signal");
+    hsa_signal_store_screlease(*handle, initial);
+    if (hsa_signal_load_scacquire(*handle) != initial) return fail(QS_ERR_HIP, "queue mode: HIP signal memory does not behave like an HSA signal");
+    return QS_OK;
+}
+
+bool chain_can_stream_order(QsEnv *e)
+{
+    int can = 0;
+    return hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, e->cfg.device) == hipSuccess && can != 0;
+}
+
+int chain_enable_stream_order(QsEnv *e)
+{
+    QsChain *c = e->chain;
+    if (!c->fwd_ptr) {
+        int r = chain_alloc_hip_signal(&c->fwd_ptr, &c->fwd, 0);
+        if (r) return r;
+        c->fwd_seq = 0;
+    }
+    for (QsChainLane &L : c->lanes) {
+        if (L.rev_ptr) continue;
+        int r = chain_alloc_hip_signal(&L.rev_ptr, &L.rev, kRevStart);
+        if (r) return r;
+        L.rev_value = kRevStart;
+    }
+    c->stream_ordered = true;
+    return QS_OK;
 }
 
 int chain_open(QsEnv *e, int nq)
@@ -1914,24 +2142,9 @@ int chain_open(QsEnv *e, int nq)
         c->have_exe = true;
         HSA_TRY(hsa_executable_load_agent_code_object(c->exe, c->gpu, c->reader, nullptr, nullptr));
         HSA_TRY(hsa_executable_freeze(c->exe, nullptr));
-        // the instantiation launch_env_on would pick for this handle
-        const int integ = e->cfg.integrator == QS_INTEG_FROZEN ? 0 : 1;
-        const int rmode = e->init ? 3 : e->cfg.randomise;
-        const int params = (rmode == 2 || e->per_env_params) ? 1 : 0;
-        static const int forced = getenv("QS_SPLIT") ? atoi(getenv("QS_SPLIT")) : -1;
-        const bool split = forced >= 0 ? forced != 0 : e->n <= kSplitMaxEnvs;
-        char sym[160];
-        snprintf(sym, sizeof sym, split ? "_ZN12_GLOBAL__N_111k_env_splitILi%dELb%dELi%dEEEvNS_8StepArgsE.kd"
-                                        : "_ZN12_GLOBAL__N_15k_envILi%dELb%dELi%dEEEvNS_8StepArgsE.kd", integ, params, rmode);
-        c->block = split ? 2 * kTile : kBlock;
-        hsa_executable_symbol_t ks;
-        HSA_TRY(hsa_executable_get_symbol_by_name(c->exe, sym, &c->gpu, &ks));
-        HSA_TRY(hsa_executable_symbol_get_info(ks, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_OBJECT, &c->kernel_object));
-        HSA_TRY(hsa_executable_symbol_get_info(ks, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_KERNARG_SEGMENT_SIZE, &c->kernarg_size));
-        HSA_TRY(hsa_executable_symbol_get_info(ks, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_GROUP_SEGMENT_SIZE, &c->group_size));
-        HSA_TRY(hsa_executable_symbol_get_info(ks, HSA_EXECUTABLE_SYMBOL_INFO_KERNEL_PRIVATE_SEGMENT_SIZE, &c->private_size));
-        if (c->kernarg_size < sizeof(StepArgs)) return fail(QS_ERR_HIP, "qs_set_queue_mode: kernel argument block is %u B, StepArgs %zu B", c->kernarg_size, sizeof(StepArgs));
-        c->stride = ((size_t)c->kernarg_size + 255) & ~size_t(255);
+        r = chain_resolve_kernel(e);
+        if (r) return r;
+        c->stride = (((size_t)c->kernarg_size + 255) & ~size_t(255)) + 256;   // room for any instantiation's hidden arguments
         // a small ring: a slot is rewritten only after its packet ran, and recently used kernarg lines are still in the caches
         // (4 096 slots: 5.43 us per step, 256: 5.27, 64 and 16: 5.24, 4: host-bound; profiles/r02/ab_experiments.txt, section E)
         c->slots = getenv("QS_CHAIN_SLOTS") ? (size_t)atoi(getenv("QS_CHAIN_SLOTS")) : 64;
@@ -1962,9 +2175,17 @@ int chain_open(QsEnv *e, int nq)
             L.slot_qidx.assign(c->slots, 0);
             HSA_TRY(hsa_signal_create(0, 0, nullptr, &L.done));
         }
-        HIP_TRY(hipMalloc((void **)&c->d_owner, (size_t)e->tiles));
+        HIP_TRY(hipMalloc((void **)&c->d_owner, (size_t)e->tiles * sizeof(unsigned)));
         HIP_TRY(hipMalloc((void **)&c->d_err, sizeof(unsigned)));
         HIP_TRY(hipMemset(c->d_err, 0, sizeof(unsigned)));
+        // stream-ordered hand-shake: needs HIP's stream memory operations and its signal memory; without them the mode
+        // stays host-ordered (round 2's contract)
+        c->out_wt = getenv("QS_CHAIN_OUT_WT") && atoi(getenv("QS_CHAIN_OUT_WT")) != 0;
+        const char *ord = getenv("QS_CHAIN_ORDER");            // "host": start with round 2's contract (A/B runs)
+        if (!(ord && ord[0] == 'h') && chain_can_stream_order(e)) {
+            r = chain_enable_stream_order(e);
+            if (r) return r;
+        }
         return QS_OK;
     };
     const int rc = body();
@@ -1972,22 +2193,35 @@ int chain_open(QsEnv *e, int nq)
     return rc;
 }
 
-// one AQL packet: the step kernel (or, kernel_object == 0, a barrier packet) behind everything enqueued before it
-uint64_t chain_write_packet(QsChain *c, QsChainLane &L, bool barrier_only, const void *kernarg, unsigned grid, int acquire, int release,
-                            bool signal)
+// one AQL packet behind everything enqueued before it on lane L (barrier bit): kind 0 the step kernel, 1 a barrier-AND packet
+// (drain), 2 an AMD barrier-value packet that holds the lane until `wait_sig` >= wait_value (the caller's stream is ready)
+enum { PKT_STEP = 0, PKT_BARRIER = 1, PKT_WAIT_VALUE = 2 };
+uint64_t chain_write_packet(QsChain *c, QsChainLane &L, int kind, const void *kernarg, unsigned grid, int acquire, int release,
+                            hsa_signal_t completion, hsa_signal_t wait_sig = hsa_signal_t{0}, int64_t wait_value = 0)
 {
     const uint64_t idx = hsa_queue_add_write_index_relaxed(L.queue, 1);
     while (idx - hsa_queue_load_read_index_scacquire(L.queue) >= L.queue->size) __builtin_ia32_pause();
     void *slot = (char *)L.queue->base_address + (idx & (L.queue->size - 1)) * 64;
-    uint16_t header;
-    if (barrier_only) {
+    uint32_t word0;                                 // header (16 bits) + the 16 bits behind it, published by ONE 32-bit store
+    const uint16_t fences = (1 << HSA_PACKET_HEADER_BARRIER) | (acquire << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
+                            (release << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
+    if (kind == PKT_BARRIER) {
         hsa_barrier_and_packet_t *p = (hsa_barrier_and_packet_t *)slot;
-        memset((char *)p + 2, 0, 62);
-        p->completion_signal = signal ? L.done : hsa_signal_t{0};
-        header = (HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE);
+        memset((char *)p + 4, 0, 60);
+        p->completion_signal = completion;
+        word0 = (uint16_t)((HSA_PACKET_TYPE_BARRIER_AND << HSA_PACKET_HEADER_TYPE) | fences);
+    } else if (kind == PKT_WAIT_VALUE) {
+        hsa_amd_barrier_value_packet_t *p = (hsa_amd_barrier_value_packet_t *)slot;
+        memset((char *)p + 4, 0, 60);
+        p->signal = wait_sig;
+        p->value = wait_value;
+        p->mask = -1;
+        p->cond = HSA_SIGNAL_CONDITION_GTE;
+        p->completion_signal = completion;
+        word0 = (uint16_t)((HSA_PACKET_TYPE_VENDOR_SPECIFIC << HSA_PACKET_HEADER_TYPE) | fences) |
+                ((uint32_t)HSA_AMD_PACKET_TYPE_BARRIER_VALUE << 16);
     } else {
         hsa_kernel_dispatch_packet_t *p = (hsa_kernel_dispatch_packet_t *)slot;
-        p->setup = 1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS;
         p->workgroup_size_x = (uint16_t)c->block; p->workgroup_size_y = 1; p->workgroup_size_z = 1;
         p->reserved0 = 0;
         p->grid_size_x = grid; p->grid_size_y = 1; p->grid_size_z = 1;
@@ -1996,12 +2230,11 @@ uint64_t chain_write_packet(QsChain *c, QsChainLane &L, bool barrier_only, const
         p->kernel_object = c->kernel_object;
         p->kernarg_address = (void *)kernarg;
         p->reserved2 = 0;
-        p->completion_signal = signal ? L.done : hsa_signal_t{0};
-        header = (HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE);
+        p->completion_signal = completion;
+        word0 = (uint16_t)((HSA_PACKET_TYPE_KERNEL_DISPATCH << HSA_PACKET_HEADER_TYPE) | fences) |
+                ((uint32_t)(1 << HSA_KERNEL_DISPATCH_PACKET_SETUP_DIMENSIONS) << 16);
     }
-    header |= (1 << HSA_PACKET_HEADER_BARRIER) | (acquire << HSA_PACKET_HEADER_SCACQUIRE_FENCE_SCOPE) |
-              (release << HSA_PACKET_HEADER_SCRELEASE_FENCE_SCOPE);
-    __atomic_store_n((uint16_t *)slot, header, __ATOMIC_RELEASE);
+    __atomic_store_n((uint32_t *)slot, word0, __ATOMIC_RELEASE);
     hsa_signal_store_screlease(L.queue->doorbell_signal, (hsa_signal_value_t)idx);
     return idx;
 }
@@ -2013,7 +2246,7 @@ int chain_drain(QsEnv *e)
     if (!c || !c->dirty) return QS_OK;
     for (QsChainLane &L : c->lanes) {
         hsa_signal_store_relaxed(L.done, 1);
-        chain_write_packet(c, L, true, nullptr, 0, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_SYSTEM, true);
+        chain_write_packet(c, L, PKT_BARRIER, nullptr, 0, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_SYSTEM, L.done);
     }
     for (QsChainLane &L : c->lanes)
         while (hsa_signal_wait_scacquire(L.done, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_ACTIVE) != 0) {}
@@ -2028,49 +2261,84 @@ int chain_drain(QsEnv *e)
     return QS_OK;
 }
 
-int chain_step(QsEnv *e, const StepArgs &A0)
+// T consecutive steps (T kernarg blocks: steps[t] differ in their I/O pointers only) on every lane, behind ONE hand-shake with
+// the handle's stream when the chain is stream-ordered
+int chain_submit(QsEnv *e, const StepArgs *steps, int64_t T)
 {
     QsChain *c = e->chain;
+    int r = chain_resolve_kernel(e);               // qs_set_params / qs_set_init_state since the last step?
+    if (r) return r;
+    if (c->stream_ordered) {
+        hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(e->stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone)
+            return fail(QS_ERR_INVALID, "queue mode: a private-queue step cannot be captured into a hipGraph (use qs_set_queue_mode(env, 0))");
+    }
     if (c->hip_dirty) {
         // HIP-side work of the handle (reset, set_state, ...) must have finished, and no tile has an owning XCD yet
-        HIP_TRY(hipMemsetAsync(c->d_owner, 0xff, (size_t)e->tiles, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
+        HIP_TRY(hipMemsetAsync(c->d_owner, 0xff, (size_t)e->tiles * sizeof(unsigned), e->stream));
+        if (!c->stream_ordered) HIP_TRY(hipStreamSynchronize(e->stream));    // stream-ordered: the write-value below is behind it
         c->hip_dirty = false;
     }
-    StepArgs A = A0;
-    A.owner = c->d_owner;
-    A.err = c->d_err;
-    // all lanes' kernarg blocks first, ONE read-back behind them, then the packets: the read-back is a PCIe round trip
-    char *ka[8];
-    size_t slot[8];
     const size_t nl = c->lanes.size();
-    for (size_t q = 0; q < nl; ++q) {
-        QsChainLane &L = c->lanes[q];
-        A.tile0 = L.tile0; A.tile_end = L.tile_end;
-        // the slot about to be rewritten belongs to step `issued - slots`, queue packet p: that kernel has FINISHED once the
-        // packet behind it has been taken off the queue (every packet carries the barrier bit): read index past p + 1
-        slot[q] = L.issued % c->slots;
-        if (L.issued >= c->slots)
-            while (hsa_queue_load_read_index_scacquire(L.queue) < L.slot_qidx[slot[q]] + 2) __builtin_ia32_pause();
-        ka[q] = L.kernargs + slot[q] * c->stride;
-        memcpy(ka[q], &A, sizeof A);
+    if (c->stream_ordered) {
+        ++c->fwd_seq;
+        HIP_TRY(hipStreamWriteValue64(e->stream, c->fwd_ptr, c->fwd_seq, 0));
+        for (QsChainLane &L : c->lanes)
+            chain_write_packet(c, L, PKT_WAIT_VALUE, nullptr, 0, HSA_FENCE_SCOPE_NONE, HSA_FENCE_SCOPE_NONE, hsa_signal_t{0}, c->fwd,
+                               (int64_t)c->fwd_seq);
     }
-    if (c->kernargs_on_device) {
-        // posted writes through the BAR: reading the last word back makes sure they have landed before a doorbell rings
-        __builtin_ia32_sfence();
-        (void)*(volatile uint32_t *)(ka[nl - 1] + sizeof A - sizeof(uint32_t));
-    }
-    for (size_t q = 0; q < nl; ++q) {
-        QsChainLane &L = c->lanes[q];
-        const int64_t tiles = L.tile_end - L.tile0;
-        const unsigned grid = c->block == 2 * kTile ? (unsigned)(tiles * c->block)
-                                                    : (unsigned)(((tiles + kBlock / kTile - 1) / (kBlock / kTile)) * kBlock);
-        L.slot_qidx[slot[q]] = chain_write_packet(c, L, false, ka[q], grid, HSA_FENCE_SCOPE_AGENT, HSA_FENCE_SCOPE_NONE, false);
-        ++L.issued;
+    for (int64_t t = 0; t < T; ++t) {
+        StepArgs A = steps[t];
+        A.owner = c->d_owner;
+        A.err = c->d_err;
+        A.out_wt = (c->stream_ordered && c->out_wt) ? 1 : 0;
+        A.dbg_shift = c->dbg_shift;
+        c->dbg_shift = 0;
+        // all lanes' kernarg blocks first, ONE read-back behind them, then the packets: the read-back is a PCIe round trip
+        char *ka[8];
+        size_t slot[8];
+        for (size_t q = 0; q < nl; ++q) {
+            QsChainLane &L = c->lanes[q];
+            A.tile0 = L.tile0; A.tile_end = L.tile_end;
+            // the slot about to be rewritten belongs to step `issued - slots`, queue packet p: that kernel has FINISHED once the
+            // packet behind it has been taken off the queue (every packet carries the barrier bit): read index past p + 1
+            slot[q] = L.issued % c->slots;
+            if (L.issued >= c->slots)
+                while (hsa_queue_load_read_index_scacquire(L.queue) < L.slot_qidx[slot[q]] + 2) __builtin_ia32_pause();
+            ka[q] = L.kernargs + slot[q] * c->stride;
+            memcpy(ka[q], &A, sizeof A);
+        }
+        if (c->kernargs_on_device) {
+            // posted writes through the BAR: reading the last word back makes sure they have landed before a doorbell rings
+            __builtin_ia32_sfence();
+            (void)*(volatile uint32_t *)(ka[nl - 1] + sizeof A - sizeof(uint32_t));
+        }
+        const bool last = t + 1 == T;
+        for (size_t q = 0; q < nl; ++q) {
+            QsChainLane &L = c->lanes[q];
+            const int64_t tiles = L.tile_end - L.tile0;
+            const unsigned grid = c->block == 2 * kTile ? (unsigned)(tiles * c->block)
+                                                        : (unsigned)(((tiles + kBlock / kTile - 1) / (kBlock / kTile)) * kBlock);
+            // stream-ordered: the LAST packet of the submission publishes -- agent-scope release (the outputs of all T steps leave
+            // the L2s; the state lines are written back too but stay valid where they are) and the completion signal the
+            // caller's stream waits for.  (QS_CHAIN_OUT_WT=1: write-through output stores on every step instead of the release;
+            // measured slower, profiles/r03/ab_experiments.txt section I.)
+            const bool sig = c->stream_ordered && last;
+            L.slot_qidx[slot[q]] = chain_write_packet(c, L, PKT_STEP, ka[q], grid, HSA_FENCE_SCOPE_AGENT,
+                                                      (sig && !c->out_wt) ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE,
+                                                      sig ? L.rev : hsa_signal_t{0});
+            ++L.issued;
+            if (sig) --L.rev_value;
+        }
     }
     c->dirty = true;
+    if (c->stream_ordered)
+        for (QsChainLane &L : c->lanes)
+            HIP_TRY(hipStreamWaitValue64(e->stream, L.rev_ptr, (uint64_t)L.rev_value, hipStreamWaitValueEq, ~0ull));
     return QS_OK;
 }
+
+int chain_step(QsEnv *e, const StepArgs &A) { return chain_submit(e, &A, 1); }
 
 // entry points that use the main stream: order it behind pending group work / the private queue first
 int main_stream_entry(QsEnv *e)
@@ -2123,10 +2391,8 @@ int qs_version(void) { return QS_VERSION; }
 #ifdef QS_STAMP
 int qs_debug_set_stamps(void *dev_ptr, uint64_t capacity_words)
 {
-    unsigned long long *p = (unsigned long long *)dev_ptr;
-    unsigned long long c = capacity_words;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_qs_stamps), &p, sizeof p) != hipSuccess) return QS_ERR_HIP;
-    if (hipMemcpyToSymbol(HIP_SYMBOL(g_qs_stamp_cap), &c, sizeof c) != hipSuccess) return QS_ERR_HIP;
+    g_host_stamps = (unsigned long long *)dev_ptr;
+    g_host_stamp_cap = capacity_words;
     return QS_OK;
 }
 #endif
@@ -2276,7 +2542,10 @@ int qs_destroy(QsEnv *e)
 
 int qs_set_stream(QsEnv *e, void *hip_stream, int32_t external)
 {
-    CHECK_ENV(e);
+    CHECK_ENV(e);                                      // drains the private queues
+    // a stream-ordered chain leaves `wait until rev == n` commands on the stream it was stepped from; they must have passed
+    // before a step is issued from another stream (which would move `rev` past n)
+    if (e->chain && e->chain->stream_ordered && e->chain->fwd_seq) HIP_TRY(hipStreamSynchronize(e->stream));
     // an owned stream is drained and destroyed; switching between caller-owned streams is the caller's ordering
     // problem (torch does it for stream capture) and must not synchronise
     if (e->own_stream) { HIP_TRY(hipStreamSynchronize(e->stream)); HIP_TRY(hipStreamDestroy(e->stream)); e->own_stream = false; }
@@ -2537,7 +2806,11 @@ int qs_step_group(QsEnv *e, int32_t g, const float *actions, float *obs, float *
     if (terminal_state && e->cfg.kind == QS_KIND_HOVERING_V0) return fail(QS_ERR_INVALID, "qs_step_group: hovering-v0 has no terminal_state");
     if (e->main_dirty) { int rc = groups_fork(e); if (rc) return rc; }
     e->groups_dirty = true;
-    return step_group_post(e, e->groups[g], actions, obs, reward, done, flags, terminal_obs, terminal_state, true);
+    int rc = step_group_post(e, e->groups[g], actions, obs, reward, done, flags, terminal_obs, terminal_state, true);
+    // with a launcher thread the record is only POSTED here; the contract (quadsim.h) lets the caller enqueue the group's
+    // policy on the group's stream right after this call, so the launch has to be on that stream before the call returns
+    group_wait_issued(e->groups[g]);
+    return rc;
 }
 
 int qs_step_groups(QsEnv *e, const float *actions, float *obs, float *reward, uint8_t *done, uint8_t *flags, float *terminal_obs,
@@ -2554,6 +2827,8 @@ int qs_step_groups(QsEnv *e, const float *actions, float *obs, float *reward, ui
         int rc = step_group_post(e, G, actions, obs, reward, done, flags, terminal_obs, terminal_state, false);
         if (rc) return rc;
     }
+    // the launcher threads issue the G launches concurrently; all of them are on their streams when the call returns
+    for (QsGroup *G : e->groups) group_wait_issued(G);
     return QS_OK;
 }
 
@@ -2608,22 +2883,30 @@ int qs_rollout_slab(QsEnv *e, int64_t T, const float *actions, float *slab, uint
 int qs_rollout_stepwise(QsEnv *e, int64_t T, const float *actions, float *obs, float *reward, uint8_t *done, uint8_t *flags)
 {
     Range rg_("qs_rollout_stepwise");
-    CHECK_ENV(e);
+    CHECK_ENV_RAW(e);
+    if (e->chain) {                                   // as qs_step_ex: packets behind the previous ones, no drain
+        if (e->groups_dirty) { int rj = groups_join(e); if (rj) return rj; HIP_TRY(hipStreamSynchronize(e->stream)); }
+    } else if (!e->groups.empty()) { int rcj = main_stream_entry(e); if (rcj) return rcj; }
     if (T < 1 || !actions || !obs || !reward || !done) return fail(QS_ERR_INVALID, "qs_rollout_stepwise: bad arguments");
     if (!e->cfg.auto_reset) return fail(QS_ERR_INVALID, "qs_rollout_stepwise: requires auto_reset");
     if (e->cfg.io_space != QS_IO_DEVICE) return fail(QS_ERR_INVALID, "qs_rollout_stepwise: device buffers only");
     const int64_t n = e->n;
     StepArgs A = make_args(e);
+    std::vector<StepArgs> steps;
+    if (e->chain) steps.reserve((size_t)T);
     for (int64_t t = 0; t < T; ++t) {
         A.actions = actions + t * n * 4;
         A.obs = obs + t * n * e->obs_dim;
         A.reward = reward + t * n;
         A.done = done + t * n;
         A.flags = flags ? flags + t * n : nullptr;
-        int r = e->chain ? chain_step(e, A) : launch_env(e, A);    // queue mode: T packets, drained by the next entry point
+        if (e->chain) { steps.push_back(A); continue; }
+        int r = launch_env(e, A);
         if (r) return r;
     }
-    return QS_OK;
+    // queue mode: T packets per queue behind ONE hand-shake with the handle's stream (stream-ordered chains), or drained by the
+    // next entry point (host-ordered chains)
+    return e->chain ? chain_submit(e, steps.data(), T) : QS_OK;
 }
 
 int qs_fill_random_actions(QsEnv *e, int64_t T, uint64_t step0, float *actions)
@@ -3079,9 +3362,39 @@ int qs_debug_chain_poison_owner(QsEnv *e)
     DeviceGuard guard(e->cfg.device);
     int rc = chain_drain(e);
     if (rc) return rc;
-    HIP_TRY(hipMemset(e->chain->d_owner, 9, (size_t)e->tiles));
+    HIP_TRY(hipMemset(e->chain->d_owner, 9, (size_t)e->tiles * sizeof(unsigned)));
     e->chain->hip_dirty = false;          // keep the poisoned owners: the next step must not reset them
     return QS_OK;
+}
+
+// Diagnostic (not in quadsim.h; tests only): the NEXT private-queue step runs with workgroup b stepping tile b + shift of its
+// launch -- every tile on another XCD than the one that holds its state -- without any synchronisation in between: the
+// placement guard must see the owner words the previous step wrote from the other XCDs.
+int qs_debug_chain_shift_once(QsEnv *e, int32_t shift)
+{
+    if (!e || !e->chain) return fail(QS_ERR_INVALID, "qs_debug_chain_shift_once: not in private-queue mode");
+    e->chain->dbg_shift = shift;
+    return QS_OK;
+}
+
+int qs_get_queue_ordering(QsEnv *e, int32_t *ordering)
+{
+    if (!e || !ordering) return fail(QS_ERR_INVALID, "qs_get_queue_ordering: null argument");
+    *ordering = (e->chain && e->chain->stream_ordered) ? QS_ORDER_STREAM : QS_ORDER_HOST;
+    return QS_OK;
+}
+
+int qs_set_queue_ordering(QsEnv *e, int32_t ordering)
+{
+    CHECK_ENV(e);                                     // drains the queues
+    if (!e->chain) return fail(QS_ERR_INVALID, "qs_set_queue_ordering: qs_set_queue_mode first");
+    if (ordering != QS_ORDER_HOST && ordering != QS_ORDER_STREAM) return fail(QS_ERR_INVALID, "qs_set_queue_ordering: unknown ordering %d", ordering);
+    QsChain *c = e->chain;
+    if (c->stream_ordered && c->fwd_seq) HIP_TRY(hipStreamSynchronize(e->stream));   // pending hand-shake waits
+    if (ordering == QS_ORDER_HOST) { c->stream_ordered = false; return QS_OK; }
+    if (!chain_can_stream_order(e))
+        return fail(QS_ERR_INVALID, "qs_set_queue_ordering: this device / HIP runtime has no stream memory operations (hipStreamWaitValue64)");
+    return chain_enable_stream_order(e);
 }
 
 int qs_get_queue_mode(QsEnv *e, int32_t *mode)

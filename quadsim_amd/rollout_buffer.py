@@ -105,6 +105,7 @@ class EpisodeTracker:
         self.ep_len = torch.zeros((n,), dtype=torch.int32, device=env.device)
         self._count = torch.zeros((1,), dtype=torch.int64, device=env.device)
         self._bufs = None
+        self._n = 0                                    # no roll-out seen yet: no episode has ended
 
     def update(self, rewards, dones, last_dones):
         """rewards [T,N]; dones [T,N] u8 (flags BEFORE each step); last_dones [N] u8 -> self (lazy results)"""
@@ -139,6 +140,10 @@ class EpisodeTracker:
         ordered: sorted by key = the reference's (step, env) order"""
         import torch
         e = self.count
+        if self._bufs is None:                         # queried before the first update()
+            dev = self.env.device
+            return (torch.empty((0,), dtype=torch.float32, device=dev), torch.empty((0,), dtype=torch.int32, device=dev),
+                    torch.empty((0,), dtype=torch.int64, device=dev))
         key, ret, ln = (b[:e] for b in self._bufs)
         if ordered and e > 1:
             key, order = torch.sort(key)

@@ -115,6 +115,7 @@ class VecDockingEnv:
         self._actions = None
         self._nstep = 0                                 # steps issued (InfoView staleness guard)
         self._groups = None
+        self._queue_private, self._queue_host_ordered = False, False
         self._pin, self._pin_i, self._act_pin = None, 0, None
         self.auto_reset = bool(auto_reset)
         # attribute surface the reference scripts poke (run_trained_docking_ppo2.py:45)
@@ -214,7 +215,7 @@ class VecDockingEnv:
                 if self._tstate is not None:
                     self._tstate = torch.empty((n, 26), dtype=torch.float32, **kw)
         self._inputs_ready()
-        if getattr(self, "_queue_private", False):
+        if self._queue_host_ordered:
             _torch().cuda.current_stream(self.device).synchronize()      # the queue is not ordered behind the caller's stream
         _lib.check(self._lib.qs_step_ex(self._h, self._ptr(self._actions), self._ptr(self._obs), self._ptr(self._rew),
                                         self._ptr(self._done), self._ptr(self._flags),
@@ -224,8 +225,8 @@ class VecDockingEnv:
 
     def step_wait(self):
         self._outputs_ready()
-        if getattr(self, "_queue_private", False):
-            self.sync()                                                    # outputs of a private-queue step: valid after the drain
+        if self._queue_host_ordered:
+            self.sync()                                                    # outputs of a host-ordered private-queue step: valid after the drain
         if self.backend == "torch":
             # done is the uint8 buffer seen as bool.  The InfoView keeps THIS step's tensors (done, flags, terminal
             # observation / states): with copy=True they are never written again, so it can be read at any time
@@ -259,21 +260,38 @@ class VecDockingEnv:
         return self.step_wait()
 
     # ------------------------------------------------------------------ private-queue mode
-    def set_queue_mode(self, private=True, queues=1):
+    def set_queue_mode(self, private=True, queues=1, ordering=None):
         """qs_set_queue_mode: step launches go to an AQL queue owned by the handle, WITHOUT the end-of-kernel cache write-back
         HIP attaches to every launch (1.6 of 6.5 us per step at 65 536 envs); results are bit-identical.  The handle's own
-        calls stay ordered (anything but a step drains the queue); tensors handed to step() must be complete when it is called
-        and its outputs are valid after sync() -- which step_wait() does in this mode, so the per-step VecEnv protocol stays
-        correct (and pays a host wait per step), while roll-outs with pre-staged actions (`rollout(actions, stepwise=True)`,
-        bench.py) enqueue all their steps and synchronise once.  queues (1..4): split the tiles over that many private queues;
-        their chains overlap each other's kernel boundary (65 536 envs: 5.2 us per step with one queue, 4.6 us with two)."""
+        calls stay ordered (anything but a step drains the queue).  ordering: "stream" (default where the device has stream
+        memory operations): a step is ordered against the env's stream -- torch's current stream -- by a GPU-side hand-shake
+        (hipStreamWriteValue64 -> barrier-value packet -> completion signal -> hipStreamWaitValue64), its outputs are stored
+        write-through, and step() / rollout(stepwise=True) involve NO host synchronisation: `obs -> policy -> step` loops run
+        as in the default mode.  "host" (round 2's contract): no hand-shake; tensors handed to step() must be complete when
+        it is called and its outputs are valid after sync() -- step_async / step_wait then synchronise the host per step.
+        queues (1..4): split the tiles over that many private queues; their chains overlap each other's kernel boundary."""
         self._use_current_stream()
         _lib.check(self._lib.qs_set_queue_mode(self._h, int(queues) if private else 0), "qs_set_queue_mode")
         self._queue_private = bool(private)
+        self._queue_host_ordered = False
+        if private:
+            if ordering is not None:
+                if ordering not in ("stream", "host"):
+                    raise ValueError("ordering must be 'stream' or 'host'")
+                _lib.check(self._lib.qs_set_queue_ordering(self._h, _lib.ORDER_STREAM if ordering == "stream" else _lib.ORDER_HOST),
+                           "qs_set_queue_ordering")
+            o = C.c_int32(0)
+            _lib.check(self._lib.qs_get_queue_ordering(self._h, C.byref(o)), "qs_get_queue_ordering")
+            self._queue_host_ordered = o.value == _lib.ORDER_HOST
 
     @property
     def queue_mode(self):
-        return "private" if getattr(self, "_queue_private", False) else "hip-stream"
+        return "private" if self._queue_private else "hip-stream"
+
+    @property
+    def queue_ordering(self):
+        """'stream' / 'host' in private-queue mode, else None (HIP-stream launches are stream-ordered by nature)"""
+        return None if not self._queue_private else ("host" if self._queue_host_ordered else "stream")
 
     # ------------------------------------------------------------------ env groups (EnvPool-style send / recv)
     def set_groups(self, groups, threads=True):
@@ -375,12 +393,12 @@ class VecDockingEnv:
             flags = torch.empty((T, n), dtype=torch.uint8, device=self.device) if want_flags else None
         fn = self._lib.qs_rollout_stepwise if stepwise else self._lib.qs_rollout
         self._inputs_ready()
-        if getattr(self, "_queue_private", False):
+        if self._queue_host_ordered:
             _torch().cuda.current_stream(self.device).synchronize()
         _lib.check(fn(self._h, T, self._ptr(actions), self._ptr(obs), self._ptr(rew), self._ptr(done),
                       self._ptr(flags)), "qs_rollout")
         self._outputs_ready()
-        if getattr(self, "_queue_private", False):
+        if self._queue_host_ordered:
             self.sync()
         return obs, rew, done, flags
 

@@ -356,8 +356,8 @@ def test_private_queue_chain_bit_identical_to_hip_stream(qa, torch, n, env_id, r
     kw = dict(num_envs=n, randomise=rnd, seed=21, init_range=qa.C3_INIT_RANGE, mass_scale=(0.8, 1.2), inertia_scale=(0.8, 1.2),
               integrator=integ, copy=False)
     a, b = qa.VecDockingEnv(env_id, **kw), qa.VecDockingEnv(env_id, **kw)
-    b.set_queue_mode(True, queues)
-    assert b.queue_mode == "private" and a.queue_mode == "hip-stream"
+    b.set_queue_mode(True, queues, ordering="host" if n == 1000 else None)    # both orderings are covered
+    assert b.queue_mode == "private" and a.queue_mode == "hip-stream" and b.queue_ordering in ("stream", "host")
     a.reset(); b.reset()
     t0 = np.zeros(n, np.float32); t0[::7] = 590.0
     a.set_state(t=t0); b.set_state(t=t0)
@@ -439,6 +439,149 @@ def test_private_queue_placement_guard_fails_loudly(qa, torch):
     env.step(acts[1])                                      # the handle recovers: owners are re-learnt after the HIP-side calls above
     assert env.step_counter == k_before + 1
     env.close()
+
+
+def test_private_queue_guard_sees_owner_words_written_by_other_xcds(qa, torch):
+    """poisoning the owner words through hipMemset (HBM-visible) never exercised cross-XCD visibility.  Here
+    the owner words are the ones the PREVIOUS packet's workgroups wrote from their own XCDs, and the next packet -- no drain,
+    no HIP call in between -- runs every workgroup one tile further, i.e. on another XCD than the one that holds the tile: the
+    guard must see those words (agent-scope atomics), store nothing and make the next synchronising call fail"""
+    n = 8192
+    lib = qa._lib.load()
+    p = lambda t: C.c_void_p(t.data_ptr())                 # noqa: E731
+    for queues in (1, 2):
+        env = qa.VecDockingEnv("docking-v0", num_envs=n, randomise=1, seed=9, init_range=qa.C3_INIT_RANGE, copy=False)
+        env.reset()
+        env.set_queue_mode(True, queues)
+        acts = env.random_actions(3, step0=0)
+        args = (p(env._obs), p(env._rew), p(env._done), p(env._flags), p(env._term))
+        assert lib.qs_step(env._h, p(acts[0]), *args) == 0     # owners claimed by the XCDs that stepped the tiles
+        assert lib.qs_step(env._h, p(acts[1]), *args) == 0     # ... and confirmed
+        torch.cuda.synchronize(); env.sync()
+        before = _full_state(env)
+        k_before = env.step_counter
+        assert lib.qs_step(env._h, p(acts[0]), *args) == 0     # re-claim after the HIP-side calls above
+        mid = None
+        assert lib.qs_debug_chain_shift_once(env._h, 1) == 0
+        assert lib.qs_step(env._h, p(acts[1]), *args) == 0     # every workgroup on the wrong XCD, straight behind the claim
+        with pytest.raises(qa.QuadsimError, match="another XCD"):
+            env.sync()
+        assert env.step_counter == k_before + 1                 # only the well-placed step counted
+        a = qa.VecDockingEnv("docking-v0", num_envs=n, randomise=1, seed=9, init_range=qa.C3_INIT_RANGE, copy=False)
+        a.reset()
+        for k in (0, 1, 0):
+            a.step(acts[k])
+        np.testing.assert_array_equal(_full_state(env), _full_state(a))     # the misplaced step stored nothing
+        env.step(acts[1]); a.step(acts[1])                      # the handle recovers
+        np.testing.assert_array_equal(_full_state(env), _full_state(a))
+        del before, mid
+        env.close(); a.close()
+
+
+@pytest.mark.parametrize("ordering", ["stream", "host"])
+def test_private_queue_follows_set_params_and_init_state(qa, torch, ordering):
+    """qs_set_params / qs_set_init_state AFTER qs_set_queue_mode change the step-kernel instantiation the
+    HIP-stream path picks per launch; the private queue must re-resolve it instead of stepping with nominal mass / resets"""
+    n = 3000
+    rs = np.random.RandomState(3)
+    kw = dict(num_envs=n, randomise=0, seed=4, copy=False)
+    a, b = qa.VecDockingEnv("docking-v0", **kw), qa.VecDockingEnv("docking-v0", **kw)
+    b.set_queue_mode(True, 2, ordering=ordering)
+    a.reset(); b.reset()
+    acts = a.random_actions(60, step0=0)
+    for e in (a, b):
+        e.step(acts[0])                                         # the chain is open and has stepped with the nominal variant
+    mass = (0.18 * rs.uniform(0.7, 1.3, n)).astype(np.float32)
+    inertia = (np.array([2.5e-4, 2.32e-4, 3.738e-4]) * rs.uniform(0.7, 1.3, (n, 3))).astype(np.float32)
+    ci = np.tile(np.array([8, -50, 5, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0], np.float32), (n, 1))
+    ci[:, 0:3] += rs.uniform(-0.4, 0.4, (n, 3)).astype(np.float32)
+    for e in (a, b):
+        e.set_params(mass, inertia)
+        e.set_init_state(ci)
+        e.set_state(t=np.full(n, 560.0, np.float32))            # every env times out inside the window: stored-init resets
+    n_done = 0
+    for k in range(1, 60):
+        oa, ra, da, _ = a.step(acts[k]); ob, rb, db, _ = b.step(acts[k])
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db), k
+        n_done += int(da.sum())
+    assert n_done >= n
+    np.testing.assert_array_equal(_full_state(a), _full_state(b))
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("n,env_id,rnd,queues", [(65536, "docking-v0", 1, 1), (65536, "docking-v0", 1, 2), (5000, "docking-v2", 2, 3)])
+def test_private_queue_stream_ordered_policy_loop(qa, torch, n, env_id, rnd, queues, monkeypatch):
+    """`obs -> torch policy (the shipped MlpPolicy) -> env.step` for 200 steps in private-queue mode
+    with the GPU-side hand-shake (hipStreamWriteValue64 -> barrier-value packet -> completion signal -> hipStreamWaitValue64)
+    and NO host synchronisation, bit-identical to the same loop on the HIP stream: every step's obs / reward / done / flags,
+    the terminal rows of every finished env, the final state (rl_baselines/ppo2/ppo2.py:472-499)"""
+    import os
+    pol = qa.MlpPolicy.from_npz(os.path.join(os.path.dirname(__file__), "golden", "policy_best_model_v0.npz"), device="cuda:0")
+    kw = dict(num_envs=n, randomise=rnd, seed=17, init_range=qa.C3_INIT_RANGE, mass_scale=(0.8, 1.2), inertia_scale=(0.8, 1.2))
+    a, b = qa.VecDockingEnv(env_id, **kw), qa.VecDockingEnv(env_id, **kw)
+    b.set_queue_mode(True, queues)
+    if b.queue_ordering != "stream":
+        pytest.skip("no stream memory operations on this device")
+    oa, ob = a.reset(), b.reset()
+    t0 = np.zeros(n, np.float32); t0[::3] = 450.0           # a third of the envs time out inside the window
+    a.set_state(t=t0); b.set_state(t=t0)
+    torch.cuda.synchronize()
+    # from here on the private-queue env must not synchronise the host
+    def no_sync(*a_, **k_):
+        raise AssertionError("host synchronisation inside the stream-ordered step loop")
+    monkeypatch.setattr(b, "sync", no_sync)
+    rec_a, rec_b = [], []
+    noise = torch.randn((200, n, 4), device="cuda", generator=torch.Generator(device="cuda").manual_seed(1)) * 0.3
+    for k in range(200):
+        for env, obs, rec in ((a, oa, rec_a), (b, ob, rec_b)):
+            act = torch.clamp(pol.predict(obs) + noise[k], -1.0, 1.0)      # policy kernels on torch's stream
+            o, r, d, info = env.step(act)
+            rec.append((o, r, d, info._dev[1], info._dev[2], info._dev[3]))
+            if env is a:
+                oa = o
+            else:
+                ob = o
+    monkeypatch.undo()
+    torch.cuda.synchronize()
+    n_done = 0
+    for k, (x, y) in enumerate(zip(rec_a, rec_b)):
+        assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) and torch.equal(x[2], y[2]) and torch.equal(x[3], y[3]), k
+        d = x[2]
+        if bool(d.any()):
+            assert torch.equal(x[4][d], y[4][d]) and torch.equal(x[5][d], y[5][d]), k
+        n_done += int(d.sum())
+    assert n_done >= n // 3
+    np.testing.assert_array_equal(_full_state(a), _full_state(b))
+    assert a.step_counter == b.step_counter == 200
+    a.close(); b.close()
+
+
+def test_threaded_group_step_is_on_its_stream_when_the_call_returns(qa, torch):
+    """with launcher threads qs_step_group only POSTED the launch; a policy kernel enqueued on the group's
+    stream right after the call could overtake it.  Policy-in-the-loop on the group streams, no join between the steps."""
+    n = 4096
+    kw = dict(num_envs=n, randomise=1, seed=3, init_range=qa.C3_INIT_RANGE)
+    a, b = qa.VecDockingEnv("docking-v0", **kw), qa.VecDockingEnv("docking-v0", **kw)
+    oa = a.reset(); ob = b.reset()
+    b.set_groups(2, threads=True)
+    b.groups_fork()
+    obs_g = []
+    for g in range(b.num_groups):
+        lo, hi = b.group_range(g)
+        obs_g.append(ob[lo:hi].clone())
+    torch.cuda.synchronize()
+    pol = lambda o: torch.tanh(o[:, 3:7] * 0.7).contiguous()      # noqa: E731
+    for k in range(50):
+        oa, _, _, _ = a.step(pol(oa))
+        for g in range(b.num_groups):
+            with torch.cuda.stream(b.group_stream(g)):
+                act = pol(obs_g[g])                               # reads what the previous step_group wrote, same stream
+            obs_g[g] = b.step_group(g, act)[0]
+    b.groups_join()
+    torch.cuda.synchronize()
+    assert torch.equal(oa, torch.cat(obs_g))
+    np.testing.assert_array_equal(_full_state(a), _full_state(b))
+    a.close(); b.close()
 
 
 def test_runner_role_split_kernel_is_bit_identical_to_one_wave_per_tile(qa):

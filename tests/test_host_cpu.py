@@ -28,7 +28,7 @@ def test_header_symbols_are_exported_by_the_library():
     for name in declared:
         assert hasattr(lib, name), "libquadsim_hip.so does not export %s" % name
     assert sorted(_lib.EXPORTS) == declared
-    assert lib.qs_version() == 120
+    assert lib.qs_version() == 130
 
 
 def test_config_struct_matches_header():
@@ -276,3 +276,19 @@ def test_packed_weight_images_match_the_library_layout():
         c, g = lane & 15, lane >> 4
         w = wt[16 * nt + c, 16 * (2 * p + (j >> 2)) + 4 * g + (j & 3)]
         assert abs((hi[nt, p, lane, j] + lo[nt, p, lane, j]) - w) <= abs(w) * 2.0 ** -16 + 1e-12
+
+
+def test_bench_maps_gpu_count_to_baseline_configs(monkeypatch):
+    """VERDICT round 2: `bench.py --gpus N` must run BASELINE's config for N (c3, c3 x2, c4, c5) and say so truthfully;
+    explicit flags override and drop the BASELINE label"""
+    import importlib
+    bench = importlib.import_module("bench")
+    want = {1: ("docking-v0", 65536, 1, "config 3"), 2: ("docking-v0", 65536, 1, "config 3 per GPU (x2)"),
+            4: ("docking-v2", 65536, 1, "config 4"), 8: ("docking-v2", 131072, 2, "config 5")}
+    for g, (env, n, rnd, tag) in want.items():
+        monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", str(g)])
+        a = bench.parse()
+        assert (a.env, a.envs_per_gpu, a.randomise, a.config_tag) == (env, n, rnd, tag)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--env", "docking-v0"])
+    a = bench.parse()
+    assert a.env == "docking-v0" and a.envs_per_gpu == 131072 and a.config_tag is None
