@@ -109,55 +109,19 @@ using namespace qs;
 
 namespace {
 
-constexpr int kTileLanes = 64;   // == qs::kTile (one wavefront)
-
-// Write-through (`sc1`) stores for the OUTPUTS of a step launched without the end-of-kernel release (StepArgs::out_wt): such a
-// launch leaves plain / `nt` stores dirty in the stepping XCD's L2, which no other queue's kernel reads; `sc1` bytes are in
-// memory once the store is acknowledged, and s_endpgm waits for every outstanding store of the wave.  The state rows keep `nt`
-// (they are meant to stay in that L2).  16-B form by inline asm (there is no 16-B atomic store); scalars by agent-scope atomics.
-typedef float qs_f4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void st_wt(qs_f4 *p, qs_f4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
-__device__ __forceinline__ void st_wt(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void st_wt(uint8_t *p, uint8_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-template <typename T> __device__ __forceinline__ void st_out(T *p, T v, int wt)
-{
-    if (wt) st_wt(p, v);
-    else QS_SO(p, v);
-}
-
-// reward / done / flags of ONE WHOLE TILE, write-through, as 16 B per lane.  A wave's scalar `sc1` store is one fabric write per
-// LANE (MI355X_MICROARCH.md: dword ~6x, byte ~12x the time per byte of a 16-B store): the three narrow rows of a tile are 192
-// such writes -- 2 us per step at 65 536 envs, measured -- against 24 when the rows pass through a wave-private LDS block
-// first: lanes 0..15 then carry the 64 rewards, lanes 16..19 the 64 done bytes, lanes 20..23 the 64 flag bytes.
-struct alignas(16) TailStage {
-    float rew[kTileLanes];
-    uint8_t done[kTileLanes], flags[kTileLanes];
-};
-__device__ __forceinline__ bool tail_rows_aligned(const float *rew_row, const uint8_t *done_row, const uint8_t *flags_row)
-{
-    return (((uintptr_t)rew_row | (uintptr_t)done_row | (uintptr_t)flags_row) & 15u) == 0;      // a null flags row is aligned
-}
-__device__ __forceinline__ void store_tail_wt(TailStage &S, int lane, float *rew_row, uint8_t *done_row, uint8_t *flags_row, float r,
-                                              uint8_t d, uint8_t f)
-{
-    S.rew[lane] = r; S.done[lane] = d; S.flags[lane] = f;
-    // same wave on both sides: LDS operations of a wave complete in order; keep the compiler from moving the reads up
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const qs_f4 *src = nullptr;
-    qs_f4 *dst = nullptr;
-    if (lane < 16) { src = reinterpret_cast<const qs_f4 *>(S.rew) + lane; dst = reinterpret_cast<qs_f4 *>(rew_row) + lane; }
-    else if (lane < 20) { src = reinterpret_cast<const qs_f4 *>(S.done) + (lane - 16); dst = reinterpret_cast<qs_f4 *>(done_row) + (lane - 16); }
-    else if (lane < 24 && flags_row) { src = reinterpret_cast<const qs_f4 *>(S.flags) + (lane - 20); dst = reinterpret_cast<qs_f4 *>(flags_row) + (lane - 20); }
-    if (dst) st_wt(dst, *src);
-    __builtin_amdgcn_wave_barrier();               // the next step's writes stay behind these reads
-}
-
 #ifndef QS_BLOCK
 #define QS_BLOCK 256
 #endif
 constexpr int kBlock = QS_BLOCK;  // 4 wavefronts = 4 tiles per workgroup
+// 1: the role-split step kernel's target wave prepares, every step, what a rocRAND reset of that step would install (state,
+// observation, per-episode parameters) in LDS, and the chaser wave's reset branch is a copy; 0 (default): the target wave
+// hands over the Philox words, the chaser wave expands them inside its branch.  Bit-identical either way.  Measured (round 3,
+// profiles/r03/ab_experiments.txt section J): 1 is SLOWER, 5.27 vs 4.72 us per step on two private queues, 7.0 vs 6.6 us on
+// the HIP stream -- every SIMD hosts one chaser and one target wave (tools/wave_map3.hip), so the target wave's time is not
+// free: the branch runs in 4 chaser waves of 5, the preparation in 5 target waves of 5, plus the LDS traffic.
+#ifndef QS_RESET_PREP
+#define QS_RESET_PREP 0
+#endif
 #ifndef QS_SPLIT_MAX_ENVS
 #define QS_SPLIT_MAX_ENVS 131072
 #endif
@@ -194,9 +158,6 @@ struct StepArgs {
                            // written and read with agent-scope atomics ONLY: like the state it guards, a plainly stored owner
                            // would stay dirty in the writing XCD's L2 and a misplaced workgroup would never see it
     unsigned *err;         // device word: bit 0 set when a workgroup found its tile owned by another XCD (it then touches nothing)
-    int out_wt;            // != 0: obs / reward / done / flags / terminal rows are stored write-through (`sc1`): a launch without the
-                           // end-of-kernel release leaves plain and `nt` stores dirty in the XCD's L2, where no other queue's kernel
-                           // would find them; write-through outputs are in memory when the packet's completion signal fires
     int dbg_shift;         // diagnostic (tests): workgroup b steps tile (b + dbg_shift) % tiles of its launch, i.e. on ANOTHER XCD
     unsigned long long *stamps;        // QS_STAMP builds: in-kernel timeline buffer (qs_debug_set_stamps), else nullptr
     unsigned long long stamp_cap, stamp_tiles;
@@ -250,12 +211,13 @@ __device__ __forceinline__ void store_par(float *__restrict__ par, int64_t tile,
     b[0] = P.m; b[kTile] = P.Ixx; b[2 * kTile] = P.Iyy; b[3 * kTile] = P.Izz;
 }
 
-__device__ __forceinline__ void store_obs(float *__restrict__ obs, int64_t env, const float o[12], int wt = 0)
+__device__ __forceinline__ void store_obs(float *__restrict__ obs, int64_t env, const float o[12])
 {
-    qs_f4 *p = reinterpret_cast<qs_f4 *>(obs + env * 12);
-    st_out(&p[0], (qs_f4{o[0], o[1], o[2], o[3]}), wt);
-    st_out(&p[1], (qs_f4{o[4], o[5], o[6], o[7]}), wt);
-    st_out(&p[2], (qs_f4{o[8], o[9], o[10], o[11]}), wt);
+    typedef float f4 __attribute__((ext_vector_type(4)));
+    f4 *p = reinterpret_cast<f4 *>(obs + env * 12);
+    QS_SO(&p[0], (f4{o[0], o[1], o[2], o[3]}));
+    QS_SO(&p[1], (f4{o[4], o[5], o[6], o[7]}));
+    QS_SO(&p[2], (f4{o[8], o[9], o[10], o[11]}));
 }
 
 // plain (cached) flavour: rows that are completed by LATER stores of the same lane (the env-major roll-out arrays, where a
@@ -350,16 +312,11 @@ __device__ __forceinline__ void maybe_reset(Env &e, Par &P, const StepArgs &A, i
 {
     done = (flags & (FLAG_OVERLIMIT | FLAG_OVERTIME)) != 0;
     if (done && A.auto_reset) {
-        if (write_term && A.term_obs) store_obs(A.term_obs, env - A.io_env0, obs, A.out_wt);
+        if (write_term && A.term_obs) store_obs(A.term_obs, env - A.io_env0, obs);
         if (write_term && A.term_state) {
             float *ts = A.term_state + (env - A.io_env0) * 26;
-            if (A.out_wt) {
 #pragma unroll
-                for (int i = 0; i < 13; ++i) { st_wt(&ts[i], e.sc[i]); st_wt(&ts[13 + i], e.st[i]); }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 13; ++i) { ts[i] = e.sc[i]; ts[13 + i] = e.st[i]; }
-            }
+            for (int i = 0; i < 13; ++i) { ts[i] = e.sc[i]; ts[13 + i] = e.st[i]; }
         }
         if (RMODE == 0) {
             // nominal states are constants: no need to re-derive their observation per lane
@@ -394,7 +351,6 @@ __device__ __forceinline__ void maybe_reset(Env &e, Par &P, const StepArgs &A, i
 template <int INTEG, bool PARAMS, int RMODE>
 __global__ __launch_bounds__(kBlock) void k_env(StepArgs A)
 {
-    __shared__ TailStage s_tail[kBlock / kTile];
     const int lane = threadIdx.x & (kTile - 1);
     const int64_t wg_tile = (int64_t)blockIdx.x * (kBlock / kTile) + (threadIdx.x >> 6);
     if (wg_tile >= A.tile_end - A.tile0) return;
@@ -436,17 +392,11 @@ __global__ __launch_bounds__(kBlock) void k_env(StepArgs A)
             for (int i = 0; i < 6; ++i) row[i] = make_float2(obs[2 * i], obs[2 * i + 1]);
             row[6] = make_float2(reward, done ? 1.0f : 0.0f);
         } else {
-            store_obs(A.obs, o, obs, A.out_wt);
-            float *rr = A.reward + (o - lane);
-            uint8_t *dr = A.done + (o - lane), *fr = A.flags ? A.flags + (o - lane) : nullptr;
-            if (A.out_wt && tile * kTile + kTile <= A.n && tail_rows_aligned(rr, dr, fr)) {
-                store_tail_wt(s_tail[threadIdx.x >> 6], lane, rr, dr, fr, reward, (uint8_t)(done ? 1 : 0), (uint8_t)flags);
-                continue;
-            }
-            st_out(&A.reward[o], reward, A.out_wt);
-            st_out(&A.done[o], (uint8_t)(done ? 1 : 0), A.out_wt);
+            store_obs(A.obs, o, obs);
+            QS_SO(&A.reward[o], reward);
+            QS_SO(&A.done[o], (uint8_t)(done ? 1 : 0));
         }
-        if (A.flags) st_out(&A.flags[o], (uint8_t)flags, A.out_wt);
+        if (A.flags) QS_SO(&A.flags[o], (uint8_t)flags);
     }
     store_env(A.st, tile, lane, e);
     if (PARAMS && RMODE == 2) store_par(A.par, tile, lane, P);
@@ -464,9 +414,17 @@ template <int INTEG, bool PARAMS, int RMODE>
 __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
 {
     __shared__ float s_tgt[13][kTile];
+#if QS_RESET_PREP
+    // [step parity][chaser reset state 13 | its observation 12 | per-episode params 4][lane]: what a reset of THIS step would
+    // install, prepared by the target wave every step off the chaser wave's critical path (the chaser wave reads step t's block
+    // while the target wave, running ahead in a roll-out, fills t+1's)
+    constexpr bool kPrep = RMODE == 1 || RMODE == 2;
+    __shared__ float s_rst[kPrep ? 2 : 1][kPrep ? 29 : 1][kTile];
+#else
+    constexpr bool kPrep = false;
     __shared__ uint4 s_phx[2][2][kTile];          // [step parity][block]: the chaser wave reads step t's words while t+1's are drawn
+#endif
     __shared__ unsigned char s_done[kTile], s_limt[kTile];
-    __shared__ TailStage s_tail;
     const int lane = threadIdx.x & (kTile - 1);
     const int role = threadIdx.x >> 6;
     const int64_t tile = launch_tile(A, blockIdx.x);   // grid = the tiles of this launch's env group
@@ -540,16 +498,11 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
             __syncthreads();                                              // #2: reset flags out, this step's Philox words in
             QS_STAMP_AT(5);
             if (rs) {
-                if (A.term_obs && active) store_obs(A.term_obs, io, obs, A.out_wt);
+                if (A.term_obs && active) store_obs(A.term_obs, io, obs);
                 if (A.term_state && active) {
                     float *ts = A.term_state + io * 26;
-                    if (A.out_wt) {
 #pragma unroll
-                        for (int i = 0; i < 13; ++i) st_wt(&ts[i], sc[i]);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 13; ++i) ts[i] = sc[i];
-                    }
+                    for (int i = 0; i < 13; ++i) ts[i] = sc[i];
                 }
                 float ic[13], it[13];
                 if (RMODE == 0) {
@@ -562,11 +515,20 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
                     for (int i = 0; i < 13; ++i) { ic[i] = src[i]; it[i] = src[13 + i]; }
                     rel_obs<false>(ic, it, obs);
                 } else {
+#if QS_RESET_PREP
+                    // the reset state, its observation and the episode's parameters were prepared by the target wave: a copy
+#pragma unroll
+                    for (int i = 0; i < 13; ++i) ic[i] = s_rst[t & 1][i][lane];
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) obs[i] = s_rst[t & 1][13 + i][lane];
+                    if (PARAMS && RMODE == 2) P = Par{s_rst[t & 1][25][lane], s_rst[t & 1][26][lane], s_rst[t & 1][27][lane], s_rst[t & 1][28][lane]};
+#else
                     const uint4 w0 = s_phx[t & 1][0][lane], w1 = s_phx[t & 1][1][lane];
                     Par Pn;
                     random_init_apply<RMODE == 2>(A.rc, w0, w1, ic, it, Pn);
                     if (PARAMS && RMODE == 2) P = Pn;
                     rel_obs<true>(ic, it, obs);
+#endif
                 }
 #pragma unroll
                 for (int i = 0; i < 13; ++i) sc[i] = ic[i];
@@ -583,17 +545,11 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
                     for (int i = 0; i < 6; ++i) row[i] = make_float2(obs[2 * i], obs[2 * i + 1]);
                     row[6] = make_float2(reward, done ? 1.0f : 0.0f);
                 } else {
-                    store_obs(A.obs, o, obs, A.out_wt);
-                    float *rr = A.reward + (o - lane);
-                    uint8_t *dr = A.done + (o - lane), *fr = A.flags ? A.flags + (o - lane) : nullptr;
-                    if (A.out_wt && tile * kTile + kTile <= A.n && tail_rows_aligned(rr, dr, fr)) {
-                        store_tail_wt(s_tail, lane, rr, dr, fr, reward, (uint8_t)(done ? 1 : 0), (uint8_t)flags);
-                        continue;
-                    }
-                    st_out(&A.reward[o], reward, A.out_wt);
-                    st_out(&A.done[o], (uint8_t)(done ? 1 : 0), A.out_wt);
+                    store_obs(A.obs, o, obs);
+                    QS_SO(&A.reward[o], reward);
+                    QS_SO(&A.done[o], (uint8_t)(done ? 1 : 0));
                 }
-                if (A.flags) st_out(&A.flags[o], (uint8_t)flags, A.out_wt);
+                if (A.flags) QS_SO(&A.flags[o], (uint8_t)flags);
             }
         }
         if (active) {
@@ -639,15 +595,35 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
             for (int i = 0; i < 13; ++i) s_tgt[i][lane] = st[i];
             s_limt[lane] = lim_t ? 1 : 0;
             uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0;
+            Par Pn = P;
             if (RMODE == 1 || RMODE == 2) {
                 random_init_words(A.rc, STREAM_AUTORESET, A.gid0 + (uint64_t)env, k + 1, w0, w1);
+#if !QS_RESET_PREP
                 s_phx[t & 1][0][lane] = w0;
                 s_phx[t & 1][1][lane] = w1;
+#endif
             }
             QS_STAMP_AT(2);
             __syncthreads();                                              // #1
             QS_STAMP_AT(3);
             if (A.T == 1) __builtin_amdgcn_s_setprio(0);
+#if QS_RESET_PREP
+            if (kPrep) {
+                // what a reset of this step would install (random_init_apply + state2rel of it: the same device functions the
+                // serial kernel runs inside its reset branch, so the same bits), computed for EVERY lane while the chaser wave
+                // evaluates state2rel and the reward; needed only after #2
+                float ic[13], it_[13], robs[12];
+                random_init_apply<RMODE == 2>(A.rc, w0, w1, ic, it_, Pn);
+                rel_obs<true>(ic, it_, robs);
+#pragma unroll
+                for (int i = 0; i < 13; ++i) s_rst[t & 1][i][lane] = ic[i];
+#pragma unroll
+                for (int i = 0; i < 12; ++i) s_rst[t & 1][13 + i][lane] = robs[i];
+                if (PARAMS && RMODE == 2) {
+                    s_rst[t & 1][25][lane] = Pn.m; s_rst[t & 1][26][lane] = Pn.Ixx; s_rst[t & 1][27][lane] = Pn.Iyy; s_rst[t & 1][28][lane] = Pn.Izz;
+                }
+            }
+#endif
             float u_t[4];
             target_control(A.C.kind, pdes, vdes, qd, 0.0f, pre, dv, P.m, u_t);   // from the state BEFORE stepping
             u_limit(u_t, P.m * kG, ut);
@@ -657,13 +633,8 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
             if (s_done[lane]) {
                 if (A.term_state && active) {
                     float *ts = A.term_state + io * 26 + 13;
-                    if (A.out_wt) {
 #pragma unroll
-                        for (int i = 0; i < 13; ++i) st_wt(&ts[i], st[i]);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 13; ++i) ts[i] = st[i];
-                    }
+                    for (int i = 0; i < 13; ++i) ts[i] = st[i];
                 }
                 float ic[13], it[13];
                 if (RMODE == 3) {
@@ -673,8 +644,10 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
                 } else {
                     nominal_init(ic, it);
                     if (PARAMS && RMODE == 2) {
-                        Par Pn;
+#if !QS_RESET_PREP
                         random_init_apply<true>(A.rc, w0, w1, ic, it, Pn);
+                        nominal_init(ic, it);
+#endif
                         P = Pn;
                     }
                 }
@@ -1900,7 +1873,6 @@ struct QsChain {
     hsa_signal_t fwd{};
     uint64_t fwd_seq = 0;             // submissions so far
     int dbg_shift = 0;                // one-shot: the next step packet runs with StepArgs::dbg_shift (placement-guard test)
-    bool out_wt = false;              // A/B knob QS_CHAIN_OUT_WT=1: write-through outputs instead of the release on the publishing packet
 };
 
 namespace {
@@ -2180,7 +2152,6 @@ int chain_open(QsEnv *e, int nq)
         HIP_TRY(hipMemset(c->d_err, 0, sizeof(unsigned)));
         // stream-ordered hand-shake: needs HIP's stream memory operations and its signal memory; without them the mode
         // stays host-ordered (round 2's contract)
-        c->out_wt = getenv("QS_CHAIN_OUT_WT") && atoi(getenv("QS_CHAIN_OUT_WT")) != 0;
         const char *ord = getenv("QS_CHAIN_ORDER");            // "host": start with round 2's contract (A/B runs)
         if (!(ord && ord[0] == 'h') && chain_can_stream_order(e)) {
             r = chain_enable_stream_order(e);
@@ -2291,7 +2262,6 @@ int chain_submit(QsEnv *e, const StepArgs *steps, int64_t T)
         StepArgs A = steps[t];
         A.owner = c->d_owner;
         A.err = c->d_err;
-        A.out_wt = (c->stream_ordered && c->out_wt) ? 1 : 0;
         A.dbg_shift = c->dbg_shift;
         c->dbg_shift = 0;
         // all lanes' kernarg blocks first, ONE read-back behind them, then the packets: the read-back is a PCIe round trip
@@ -2321,12 +2291,12 @@ int chain_submit(QsEnv *e, const StepArgs *steps, int64_t T)
                                                         : (unsigned)(((tiles + kBlock / kTile - 1) / (kBlock / kTile)) * kBlock);
             // stream-ordered: the LAST packet of the submission publishes -- agent-scope release (the outputs of all T steps leave
             // the L2s; the state lines are written back too but stay valid where they are) and the completion signal the
-            // caller's stream waits for.  (QS_CHAIN_OUT_WT=1: write-through output stores on every step instead of the release;
-            // measured slower, profiles/r03/ab_experiments.txt section I.)
+            // caller's stream waits for.  (Write-through `sc1` output stores on every step instead of this release were built
+            // and measured: 6.90 against 5.74 us per step in a 600-step roll-out, and they cost the ordinary launches 0.9 us
+            // through the store code they displaced; profiles/r03/ab_experiments.txt section I.)
             const bool sig = c->stream_ordered && last;
             L.slot_qidx[slot[q]] = chain_write_packet(c, L, PKT_STEP, ka[q], grid, HSA_FENCE_SCOPE_AGENT,
-                                                      (sig && !c->out_wt) ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE,
-                                                      sig ? L.rev : hsa_signal_t{0});
+                                                      sig ? HSA_FENCE_SCOPE_AGENT : HSA_FENCE_SCOPE_NONE, sig ? L.rev : hsa_signal_t{0});
             ++L.issued;
             if (sig) --L.rev_value;
         }

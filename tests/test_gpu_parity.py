@@ -31,11 +31,13 @@ def test_g1_drone_step_golden(qa):
 def test_g3_controller_golden(qa):
     g = load_golden("g3_controller")
     u, sd = qa.ctrl_batch(0, g["state_des"], g["state_now"], mass=float(g["mass"]))
-    # moments are -10 x (difference of euler angles of O(1)): absolute floor 1e-5 x 10
-    np.testing.assert_allclose(u, g["u_pid"], rtol=1e-5, atol=1e-4)
+    # moments are -10 x (difference of euler angles of O(1)): the absolute floor is ~10 x the angles' 1e-6.  Measured on
+    # MI355X (tools/measure_tolerances.py): max |du| 5.9e-6 on the moments (PID), 5.1e-6 (vel_controller), thrust 1.4e-5 on
+    # values up to 57 (inside rtol) -> atol = 2e-5, ~3x the observed error (was 1e-4)
+    np.testing.assert_allclose(u, g["u_pid"], rtol=1e-5, atol=2e-5)
     np.testing.assert_allclose(sd, g["state_des_after_pid"], **STATE_TOL)
     u, sd = qa.ctrl_batch(1, g["state_des"], g["state_now"], g["state_last"], mass=float(g["mass"]))
-    np.testing.assert_allclose(u, g["u_vel"], rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(u, g["u_vel"], rtol=1e-5, atol=2e-5)
     np.testing.assert_allclose(sd, g["state_des_after_vel"], **STATE_TOL)
 
 
@@ -132,8 +134,11 @@ def test_closed_loop_single_env_gym_protocol(qa, name, env_id):
     for t in range(T):
         obs, rew, done, info = env.step(g["actions"][t])
         assert done == bool(g["done"][t]), t
-        np.testing.assert_allclose(obs, g["obs"][t], rtol=1e-3, atol=1e-3)
-        assert abs(rew - g["reward"][t]) < 1e-3
+        # free-running float32 against the float64 reference: the error accumulates over an episode (<= 40 / 75 steps).
+        # Measured over these 400 steps: max |obs - ref| 1.3e-5 (v0) / 3.9e-5 (v2), max |reward - ref| 5.4e-6 -> 1e-4 and
+        # 2e-5, ~2.5-4x the observed error (were 1e-3 both)
+        np.testing.assert_allclose(obs, g["obs"][t], rtol=1e-5, atol=1e-4)
+        assert abs(rew - g["reward"][t]) < 2e-5
         assert info["flag_docking"] == bool(g["flags"][t] & 1) and info["done_overlimit"] == bool(g["flags"][t] & 2)
         if done:
             obs = env.reset()

@@ -55,9 +55,11 @@ h = env._h
 p = lambda t: C.c_void_p(t.data_ptr())            # noqa: E731
 io = (p(env._obs), p(env._rew), p(env._done), p(env._flags), p(env._term), None)
 torch.cuda.synchronize()
-for rep in range(6):                       # the last 64 steps overwrite the earlier ones (slot = step counter mod 64)
-    for k in range(64):
-        lib.qs_step_groups(h, p(pool[k % args.pool]), *io)
+aptr = [p(pool[i]) for i in range(args.pool)]
+seq = [aptr[k % args.pool] for k in range(6 * 64 + 640)]   # laid out beforehand: a tensor index per step would make the host the limit
+step = lib.qs_step_groups
+for a in seq:                              # the last 64 steps overwrite the earlier ones (slot = step counter mod 64)
+    step(h, a, *io)
 env.sync()
 torch.cuda.synchronize()
 light = "stamp2" in os.environ.get("QUADSIM_HIP_LIB", "")
