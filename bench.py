@@ -502,21 +502,27 @@ def main():
             (lib.qs_step_groups(h, aptr[k % P], obs, rew, done, flags, term, None) if G > 1 else
              lib.qs_step(h, aptr[k % P], obs, rew, done, flags, term))
         barrier()
-        env.timer_start()                    # event on the main stream; group streams are ordered behind it
-        t0 = time.perf_counter()
-        if G > 1:
-            qs = lib.qs_step_groups
-            for a in seq:
-                qs(h, a, obs, rew, done, flags, term, None)
-        else:
-            qs = lib.qs_step
-            for a in seq:
-                qs(h, a, obs, rew, done, flags, term)
-        ev_ms = env.timer_stop()             # joins the group streams / drains the private queues, records the stop event
+        err = None
+        try:
+            env.timer_start()                # event on the main stream; group streams are ordered behind it
+            t0 = time.perf_counter()
+            if G > 1:
+                qs = lib.qs_step_groups
+                for a in seq:
+                    qs(h, a, obs, rew, done, flags, term, None)
+            else:
+                qs = lib.qs_step
+                for a in seq:
+                    qs(h, a, obs, rew, done, flags, term)
+            ev_ms = env.timer_stop()         # joins the group streams / drains the private queues, records the stop event
+        except qa.QuadsimError as ex:        # the private queues' placement guard (reported by the draining call)
+            err, ev_ms, t0 = str(ex), float("nan"), time.perf_counter()
         torch.cuda.synchronize()
         wall = time.perf_counter() - t0
         if distributed:
             dist.barrier()
+        if max_over_ranks(1.0 if err else 0.0) > 0.5:      # every rank raises together: the callers hold collectives
+            raise qa.QuadsimError(err or "the private-queue placement guard fired on another rank")
         return max_over_ranks(wall), ev_ms
 
     def verify_private_queue(mk, pool, queues=1):
@@ -557,7 +563,12 @@ def main():
                     raise SystemExit("--queue-mode private: " + notes[-1])
                 continue
             env.set_queue_mode(True, q, ordering="host")
-            t = time_steps(env, probe, 1, 50, pool)[0]
+            try:
+                t = time_steps(env, probe, 1, 50, pool)[0]
+            except qa.QuadsimError as ex:
+                notes.append("%d private queue(s) not used: %s" % (q, ex))
+                env.reset()
+                continue
             notes.append("%d private queue(s): %.2f us per step on the probe" % (q, t / probe * 1e6))
             if t < best_t:
                 best_t, queues = t, q
@@ -576,7 +587,26 @@ def main():
     P = max(1, min(args.action_pool, K * R, (1 << 29) // (n * 16)))      # at most 512 MiB of action batches
     pool = env.random_actions(P, step0=0)               # [P,N,4] U(-1,1), resident in HBM before timing
     queue_mode, queues, queue_note = pick_launch_path(env, lambda: make_env(args.integrator), pool, max(200, min(1000, K)))
-    runs = [time_steps(env, K, R, W, pool, groups) for _ in range(max(1, args.repeats))]
+    try:
+        runs = [time_steps(env, K, R, W, pool, groups) for _ in range(max(1, args.repeats))]
+        guard = None
+    except qa.QuadsimError as ex:
+        # the private queue's placement guard fired while timing (seen when several processes share one GPU: another process's
+        # queues in flight change where the dispatcher deals the workgroups): the handle failed loudly, as designed -- the
+        # release-free chain cannot be used here, so the HIP-stream chain is what is timed (time_steps raises on every rank)
+        if queue_mode != "private":
+            raise
+        guard = str(ex)
+    if guard is not None:
+        queue_note = ((queue_note + "; ") if queue_note else "") + (
+            "private queues ABANDONED during timing: %s -- timed on the HIP stream instead" % guard)
+        queue_mode, queues = "hip", 0
+        try:
+            env.set_queue_mode(False)
+        except qa.QuadsimError:
+            env.set_queue_mode(False)                       # the first call reports the pending error, the second switches
+        env.reset()
+        runs = [time_steps(env, K, R, W, pool, groups) for _ in range(max(1, args.repeats))]
     order = sorted(range(len(runs)), key=lambda i: runs[i][0])
     wall, ev_ms = runs[order[len(order) // 2]]
     steps_timed = K * R
@@ -696,18 +726,24 @@ def main():
         # the headline cycles several hundred distinct action batches (every step reads actions the caches have never seen);
         # straight behind a policy kernel the actions are cache-resident instead: the same chain with a 16-batch pool
         best = None
-        for q in (1, 2):
-            env.set_queue_mode(True, q, ordering="host")
-            wq, _ = time_steps(env, K, R, min(W, 50), pool[:16])
-            if best is None or wq < best[0]:
-                best = (wq, q)
-        out["actions_cache_resident"] = {"value": total_envs * steps_timed / best[0], "unit": "env-steps/s", "private_queues": best[1],
-                                         "step_period_us": best[0] * 1e6 / steps_timed,
-                                         "frac": frac_of(best[0] * 1e6 / steps_timed),
-                                         "what": "16-batch action pool (%d MB) instead of the headline's %d batches (%.0f MB)"
-                                                 % (16 * n * 16 // 1000000, P, P * n * 16 / 1e6)}
-        env.set_queue_mode(True, queues, ordering="host")
-    if queue_mode == "private":
+        try:
+            for q in (1, 2):
+                env.set_queue_mode(True, q, ordering="host")
+                wq, _ = time_steps(env, K, R, min(W, 50), pool[:16])
+                if best is None or wq < best[0]:
+                    best = (wq, q)
+            out["actions_cache_resident"] = {"value": total_envs * steps_timed / best[0], "unit": "env-steps/s", "private_queues": best[1],
+                                             "step_period_us": best[0] * 1e6 / steps_timed,
+                                             "frac": frac_of(best[0] * 1e6 / steps_timed),
+                                             "what": "16-batch action pool (%d MB) instead of the headline's %d batches (%.0f MB)"
+                                                     % (16 * n * 16 // 1000000, P, P * n * 16 / 1e6)}
+            env.set_queue_mode(True, queues, ordering="host")
+        except qa.QuadsimError as ex:
+            out["actions_cache_resident"] = {"invalid": "the placement guard fired during this leg: %s" % ex}
+            env.reset()
+    if queue_mode == "private" and args.no_extras:
+        env.set_queue_mode(False)                          # nothing below steps this env again (profiling runs: no HIP-stream twin)
+    elif queue_mode == "private":
         # the same chain as ordinary HIP launches: every kernel ends with the agent-scope release, i.e. every step's outputs are
         # consumable by the next kernel on the stream -- the rate of a per-step `obs -> policy -> env.step` loop's env side
         env.set_queue_mode(False)
@@ -744,9 +780,19 @@ def main():
 
 def extras(args, out, env, pool, make_env, time_steps, verify_private_queue, barrier, max_over_ranks, queue_mode, queues, X):
     """every leg beside the headline; each under its own name in the line"""
-    import ctypes as C
     import torch
     import torch.distributed as dist
+    import quadsim_amd as qa
+
+    def leave_private(e):
+        """back to the HIP stream; a pending placement error (see main) is reported by the first call and cleared"""
+        try:
+            e.set_queue_mode(False)
+            return None
+        except qa.QuadsimError as ex:
+            e.set_queue_mode(False)
+            e.reset()
+            return str(ex)
     n, world, rank, local_rank, total_envs = X["n"], X["world"], X["rank"], X["local_rank"], X["total_envs"]
     K, R, W, P, bpe, rbpe, groups, steps_timed = X["K"], X["R"], X["W"], X["P"], X["bpe"], X["rbpe"], X["groups"], X["steps_timed"]
     frac_of = lambda us, b=bpe, nn=n: b * nn / (us * 1e-6) / 1e9 / HBM_PEAK_GBS      # noqa: E731
@@ -780,12 +826,16 @@ def extras(args, out, env, pool, make_env, time_steps, verify_private_queue, bar
         ro[mode] = {"value": total_envs / wr, "unit": "env-steps/s", "step_period_us": wr * 1e6, "frac": frac_of(wr * 1e6),
                     "read_frac": frac_of(wr * 1e6, rbpe)}
         del bufs
+        if mode != "hip":
+            err = leave_private(env)
+            if err:
+                ro[mode] = {"invalid": "the placement guard fired during this leg (several processes on one GPU?): " + err}
     ro["T"] = Tr
     ro["what"] = ("qs_rollout_stepwise: T single-step launches per call, outputs of all T steps kept ([T,N,12] obs, [T,N] reward / done / "
                   "flags, %.1f GB per call) and consumable in stream order when the call's hand-shake passes" % (Tr * n * 54 / 1e9))
     out["rollout_stepwise"] = ro
     del acts_r
-    env.set_queue_mode(False)
+    leave_private(env)
     # ---- policy BETWEEN the steps (rl_baselines/ppo2/ppo2.py:472-499): obs -> the shipped MlpPolicy (three torch GEMMs +
     #      activations on torch's stream) -> env.step, nothing pre-staged, no host synchronisation in either launch path
     wpath = os.path.join(ROOT, "tests", "golden", "policy_best_model_v0.npz")
@@ -813,14 +863,17 @@ def extras(args, out, env, pool, make_env, time_steps, verify_private_queue, bar
         # the env side alone, per-step consumable, from the raw C-ABI loop: HIP stream = `hip_stream_mode`; private queue with the
         # per-step hand-shake (hipStreamWriteValue64 + hipStreamWaitValue64 per step are host-bound)
         if "private_stream_ordered" in pb:
-            ws, _ = time_steps(env, 500, 1, 50, pool[:16])
-            pb["private_stream_ordered"]["env_step_alone_us"] = ws / 500 * 1e6
+            try:
+                ws, _ = time_steps(env, 500, 1, 50, pool[:16])
+                pb["private_stream_ordered"]["env_step_alone_us"] = ws / 500 * 1e6
+            except qa.QuadsimError as ex:
+                pb["private_stream_ordered"] = {"invalid": "the placement guard fired during this leg: %s" % ex}
         pb["what"] = ("VecDockingEnv.step(MlpPolicy.predict(obs)) per step, 300 steps; the policy is three torch GEMMs and dominates "
                       "both; per-step consumable outputs cost a release per step in either path, so the private queue buys nothing "
                       "here (DESIGN.md section 4a): use the HIP-stream mode for per-step loops, the fused qs_policy_rollout / "
                       "qs_runner_rollout kernels for throughput")
         out["policy_between_steps"] = pb
-        env.set_queue_mode(False)
+        leave_private(env)
     # fused roll-out leg: T steps per launch, state in registers (different algorithmic bytes: see DESIGN.md)
     T = args.rollout_T
     acts = pool[:T] if P >= T else env.random_actions(T)
@@ -860,7 +913,17 @@ def extras(args, out, env, pool, make_env, time_steps, verify_private_queue, bar
             e2.reset()
             pool2 = e2.random_actions(min(128, P), step0=0)
             qm, qq, note = _pick(args, e2, mk, pool2, time_steps, verify_private_queue, max_over_ranks, groups)
-            w5 = sorted(time_steps(e2, K, R, min(W, 50), pool2)[0] for _ in range(3))[1]
+            try:
+                w5 = sorted(time_steps(e2, K, R, min(W, 50), pool2)[0] for _ in range(3))[1]
+                bad = 0.0
+            except qa.QuadsimError:
+                bad = 1.0
+            if max_over_ranks(bad) > 0.5:                   # placement guard fired on some rank: time the HIP-stream chain
+                note = (note or "") + "; private queues abandoned during timing (placement guard): timed on the HIP stream"
+                qm, qq = "hip", 0
+                leave_private(e2)
+                e2.reset()
+                w5 = sorted(time_steps(e2, K, R, min(W, 50), pool2)[0] for _ in range(3))[1]
             us = w5 * 1e6 / steps_timed
             legs[key] = {"envs_per_gpu": nb, "value": nb * world / (us * 1e-6), "unit": "env-steps/s", "step_period_us": us,
                          "bytes_per_env_step": b_, "frac": b_ * nb / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
@@ -959,7 +1022,12 @@ def _pick(args, env, mk, pool, time_steps, verify_private_queue, max_over_ranks,
             notes.append("%d private queue(s) not used: %s" % (q, why if not ok else "another rank could not verify it"))
             continue
         env.set_queue_mode(True, q, ordering="host")
-        t = time_steps(env, 300, 1, 50, pool)[0]
+        try:
+            t = time_steps(env, 300, 1, 50, pool)[0]
+        except Exception as ex:                              # noqa: BLE001  (the placement guard: QuadsimError)
+            notes.append("%d private queue(s) not used: %s" % (q, ex))
+            env.reset()
+            continue
         notes.append("%d private queue(s): %.2f us per step on the probe" % (q, t / 300 * 1e6))
         if t < best_t:
             best_t, queues = t, q

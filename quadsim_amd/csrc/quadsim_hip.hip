@@ -57,15 +57,35 @@ using namespace qs;
 // The stamp buffer travels in StepArgs (not in a __device__ global): the private-queue launches run a second copy of the code
 // object, loaded through HSA, whose globals HIP's hipMemcpyToSymbol never reaches.
 // stamps stay in registers until the wave's last instruction: a store next to a barrier would be waited for by it
-#define QS_STAMP_DECL unsigned long long stamp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-// -DQS_STAMP=2 ("light"): only the first and the last stamps of a wave (start; stores drained) and no extra waits in between --
-// every s_memrealtime is a scalar-memory round trip, eight of them and the load-landed waits cost ~0.7 us per step, too much
-// for a timeline whose PERIOD is to be compared with the unstamped chain
+#define QS_STAMP_DECL unsigned long long stamp_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; (void)stamp_
+// -DQS_STAMP=2 ("light"): only the first and the last stamp of a wave.  The first stays in a register; the last -- taken when
+// all of the wave's stores have been ISSUED, not drained -- is stored together with it by lane 0 (two 8-byte stores, never waited
+// for).  The full build's eight scalar-memory round trips, its load-landed waits and, above all, its flush of eight stores
+// BEHIND the drained wave end (a store-acknowledge latency on every workgroup's tail) cost ~0.7-0.9 us per step: too much for a
+// timeline whose PERIOD is to be compared with the unstamped chain.  Even two stamps per wave cost ~0.4 us per step when every
+// workgroup takes them (each is a scalar-memory round trip at the wave's head / tail), so only one workgroup in 64 does.
 #if QS_STAMP + 0 >= 2
-#define QS_STAMP_AT(slot) ((void)((((slot) == 0) || ((slot) >= 6)) ? (stamp_[slot] = __builtin_amdgcn_s_memrealtime()) : 0ull))
+#define QS_STAMP_AT(slot)                                                                                       \
+    do {                                                                                                        \
+        /* no control flow near the loads: the first stamp is taken unconditionally (a scalar-memory read nobody waits */ \
+        /* for until the wave's end); a branch here changes where the compiler waits for the state rows (+0.8 us)       */ \
+        /* ... and it is taken at stamp site 1, BEHIND the issue of the wave's state loads (~50 ns after the wave's start): a  */ \
+        /* scalar-memory read in front of them delays every later s_waitcnt lgkmcnt(0), i.e. the loads' addresses              */ \
+        if ((slot) == 1) stamp_[0] = __builtin_amdgcn_s_memrealtime();                                          \
+        else if ((slot) == (role == 0 ? 7 : 6)) {                                                               \
+            if (lane == 0 && A.stamps && (tile & 63) == 0) {     /* one workgroup in 64 records */               \
+                const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();                               \
+                const unsigned long long ix_ = ((k0 % 64ull) * (unsigned long long)(A.stamp_tiles) + (unsigned long long)tile) * 16ull + 8 * role; \
+                if (ix_ + 8 <= A.stamp_cap) { A.stamps[ix_] = stamp_[0]; A.stamps[ix_ + (slot)] = now_; }       \
+            }                                                                                                   \
+        }                                                                                                       \
+    } while (0)
 #else
 #define QS_STAMP_AT(slot) (stamp_[slot] = __builtin_amdgcn_s_memrealtime())
 #endif
+#if QS_STAMP + 0 >= 2
+#define QS_STAMP_FLUSH() ((void)0)
+#else
 #define QS_STAMP_FLUSH()                                                                                        \
     do {                                                                                                        \
         if (lane == 0 && A.stamps) {                                                                            \
@@ -73,6 +93,7 @@ using namespace qs;
             if (ix_ + 8 <= A.stamp_cap) for (int j_ = 0; j_ < 8; ++j_) A.stamps[ix_ + j_] = stamp_[j_];          \
         }                                                                                                       \
     } while (0)
+#endif
 // runner kernels: phase durations summed over the T steps of one launch, [tile][role][8] words
 #define QS_PHASE_DECL unsigned long long ph_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ph_t_ = __builtin_amdgcn_s_memrealtime(); \
     const unsigned long long ph_c0_ = __builtin_amdgcn_s_memtime(), ph_r0_ = ph_t_
@@ -562,7 +583,7 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
             if (PARAMS && RMODE == 2) store_par(A.par, tile, lane, P);
         }
         if (!A.owner || active || env >= A.n) step_counter_end(A, tile, lane, k0);   // a misplaced tile's counter stays put, too
-#ifdef QS_STAMP
+#if defined(QS_STAMP) && QS_STAMP + 0 < 2
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
         QS_STAMP_AT(7);

@@ -1,6 +1,6 @@
 # One GPU-box round of the evidence DESIGN.md section 5 quotes (round 3).  Run via gpurun from the repo root, AFTER
 # tools/build_stamp.sh in the build container (the stamped twins travel with the snapshot).
-#   1. in-kernel s_memrealtime timelines of the step chain: HIP stream, 1 and 2 private queues (light stamps: period / span / gap of
+#   1. in-kernel s_memrealtime timelines of the step chain: HIP stream, 1 / 2 / 3 private queues (light stamps: period / span / gap of
 #      the unperturbed chain; full stamps: the phase budget)
 #   2. rocprofv3 --kernel-trace --stats of the same command in both launch paths, each with a sidecar json that records the launch
 #      shape the profile was TAKEN with (bench.py computes rocprof_*.kernel_frac from it)
@@ -9,7 +9,7 @@ set -o pipefail
 R=$(pwd); OUT=$R/gpurun_out/r03; mkdir -p $OUT
 export TMPDIR=/tmp
 L2=$R/quadsim_amd/csrc/libquadsim_hip_stamp2.so; L1=$R/quadsim_amd/csrc/libquadsim_hip_stamp.so
-for Q in 1 2; do
+for Q in 1 2 3; do
   QUADSIM_HIP_LIB=$L2 timeout -k 10 120 python3 tools/stamp_timeline.py --queue-mode private --queues $Q --ordering host --pool 512 \
       --json $OUT/step_kernel_timeline_private_q$Q.json > $OUT/step_kernel_timeline_private_q$Q.txt 2>&1 || echo "stamp private q$Q failed"
 done
