@@ -191,8 +191,9 @@ int qs_groups_join(QsEnv *env);
  *     qs_sync() (or any other entry point);
  *   - every workgroup checks that it runs on the XCD that holds its tile (the hardware deals blocks to XCDs round-robin
  *     from a fixed start; HIP does not promise it): the owning XCD of a tile is kept in a word that is only accessed by
- *     agent-scope atomics, so every XCD sees it; if the check ever fails the workgroup touches nothing and the next
- *     synchronising call (qs_sync, qs_get_state, ...) returns QS_ERR_HIP.
+ *     agent-scope atomics, so every XCD sees it; if the check ever fails the workgroup touches nothing, raises an error
+ *     word in host memory, and both the next step call and the next synchronising call (qs_sync, qs_get_state, ...)
+ *     return QS_ERR_HIP -- a loop of nothing but steps cannot run on unnoticed; the synchronising call re-arms the handle.
  * mode = the number of private queues, 1..4: with more than one, the tiles are split into that many contiguous ranges and
  * every step writes one packet per queue -- the chains then overlap each other's kernel boundary (65 536 envs: 5.2 us per
  * step with one queue, 4.6 us with two; without the release there is no chip-wide write-back for them to collide on).

@@ -290,7 +290,7 @@ __device__ __forceinline__ bool chain_owner_mismatch(const StepArgs &A, int64_t 
         if (own == kUnowned) return false;
     }
     if (own != xcc) {
-        if (lane == 0) __hip_atomic_fetch_or(A.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane == 0) __hip_atomic_fetch_or(A.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // host memory
         return true;
     }
     return false;
@@ -1884,7 +1884,9 @@ struct QsChain {
     unsigned block = 0;
     size_t stride = 0, slots = 0;
     unsigned *d_owner = nullptr;      // [tiles] 32-bit words, agent-scope atomics only
-    unsigned *d_err = nullptr;
+    unsigned *d_err = nullptr;        // the placement guard's error word: pinned, coherent HOST memory (d_err = its device address) -- a
+    volatile unsigned *h_err = nullptr;   // misplaced workgroup sets it with a system-scope atomic, and every later submission sees it
+                                          // without a synchronisation: a stream-ordered loop that never drains still fails within a few steps
     bool kernargs_on_device = false;  // kernarg ring in BAR-mapped device memory (else: host memory, correct but slow)
     bool dirty = false;               // packets enqueued since the last drain
     bool hip_dirty = true;            // the handle did HIP-side work since the last packet
@@ -2032,7 +2034,7 @@ void chain_close(QsEnv *e)
     if (c->have_exe) hsa_executable_destroy(c->exe);
     if (c->have_reader) hsa_code_object_reader_destroy(c->reader);
     if (c->d_owner) (void)hipFree(c->d_owner);
-    if (c->d_err) (void)hipFree(c->d_err);
+    if (c->h_err) (void)hipHostFree((void *)c->h_err);
     delete c;
     e->chain = nullptr;
 }
@@ -2169,8 +2171,9 @@ int chain_open(QsEnv *e, int nq)
             HSA_TRY(hsa_signal_create(0, 0, nullptr, &L.done));
         }
         HIP_TRY(hipMalloc((void **)&c->d_owner, (size_t)e->tiles * sizeof(unsigned)));
-        HIP_TRY(hipMalloc((void **)&c->d_err, sizeof(unsigned)));
-        HIP_TRY(hipMemset(c->d_err, 0, sizeof(unsigned)));
+        HIP_TRY(hipHostMalloc((void **)&c->h_err, 64, hipHostMallocMapped | hipHostMallocCoherent));
+        *c->h_err = 0;
+        HIP_TRY(hipHostGetDevicePointer((void **)&c->d_err, (void *)c->h_err, 0));
         // stream-ordered hand-shake: needs HIP's stream memory operations and its signal memory; without them the mode
         // stays host-ordered (round 2's contract)
         const char *ord = getenv("QS_CHAIN_ORDER");            // "host": start with round 2's contract (A/B runs)
@@ -2243,10 +2246,8 @@ int chain_drain(QsEnv *e)
     for (QsChainLane &L : c->lanes)
         while (hsa_signal_wait_scacquire(L.done, HSA_SIGNAL_CONDITION_LT, 1, UINT64_MAX, HSA_WAIT_STATE_ACTIVE) != 0) {}
     c->dirty = false;
-    unsigned err = 0;
-    HIP_TRY(hipMemcpy(&err, c->d_err, sizeof err, hipMemcpyDeviceToHost));
-    if (err) {
-        (void)hipMemset(c->d_err, 0, sizeof err);
+    if (*c->h_err) {
+        *c->h_err = 0;
         return fail(QS_ERR_HIP, "queue mode: a workgroup ran on another XCD than the one holding its tile; the steps since the last "
                                 "synchronisation are invalid (this placement is not promised by HIP: use qs_set_queue_mode(env, 0))");
     }
@@ -2258,6 +2259,13 @@ int chain_drain(QsEnv *e)
 int chain_submit(QsEnv *e, const StepArgs *steps, int64_t T)
 {
     QsChain *c = e->chain;
+    if (*c->h_err) {
+        // a workgroup of an EARLIER step found its tile on another XCD (the word is host memory: no synchronisation needed to see
+        // it).  Reported here as well as at the next drain, so that a loop of nothing but steps cannot run on unnoticed; the flag
+        // stays set until a draining call has reported it and re-armed the handle.
+        return fail(QS_ERR_HIP, "queue mode: a workgroup ran on another XCD than the one holding its tile; the steps since the last "
+                                "synchronisation are invalid (call qs_sync, then continue or use qs_set_queue_mode(env, 0))");
+    }
     int r = chain_resolve_kernel(e);               // qs_set_params / qs_set_init_state since the last step?
     if (r) return r;
     if (c->stream_ordered) {

@@ -479,6 +479,36 @@ def test_private_queue_guard_sees_owner_words_written_by_other_xcds(qa, torch):
 
 
 @pytest.mark.parametrize("ordering", ["stream", "host"])
+def test_private_queue_guard_reports_without_a_synchronisation(qa, torch, ordering):
+    """a loop of nothing but steps (the stream-ordered mode never drains) must not run on after a misplacement: the error word is
+    host memory, every submission looks at it, so qs_step itself starts failing within a few calls"""
+    n = 4096
+    lib = qa._lib.load()
+    p = lambda t: C.c_void_p(t.data_ptr())                 # noqa: E731
+    env = qa.VecDockingEnv("docking-v0", num_envs=n, randomise=1, seed=9, init_range=qa.C3_INIT_RANGE, copy=False)
+    env.reset()
+    env.set_queue_mode(True, 1, ordering=ordering)
+    acts = env.random_actions(2, step0=0)
+    args = (p(env._obs), p(env._rew), p(env._done), p(env._flags), p(env._term))
+    assert lib.qs_step(env._h, p(acts[0]), *args) == 0
+    assert lib.qs_debug_chain_shift_once(env._h, 1) == 0
+    assert lib.qs_step(env._h, p(acts[1]), *args) == 0     # every workgroup misplaced; nobody synchronises
+    failed_at = None
+    for k in range(400):
+        if lib.qs_step(env._h, p(acts[k & 1]), *args) != 0:
+            failed_at = k
+            break
+    assert failed_at is not None, "400 further steps were accepted after a misplaced one"
+    assert b"another XCD" in lib.qs_last_error()
+    with pytest.raises(qa.QuadsimError, match="another XCD"):
+        env.sync()                                          # the draining call reports it too, and re-arms the handle
+    torch.cuda.synchronize()
+    env.step(acts[0])                                       # usable again
+    env.sync()
+    env.close()
+
+
+@pytest.mark.parametrize("ordering", ["stream", "host"])
 def test_private_queue_follows_set_params_and_init_state(qa, torch, ordering):
     """qs_set_params / qs_set_init_state AFTER qs_set_queue_mode change the step-kernel instantiation the
     HIP-stream path picks per launch; the private queue must re-resolve it instead of stepping with nominal mass / resets"""
