@@ -567,8 +567,14 @@ static float u16f(uint32_t h) { return fmaf((float)h, 1.52587890625e-05f, 7.6293
  * v0/v2; the ranges are the commented-out lines docking_env.py:34-37).
  * rr[0..3] = half-ranges for chaser pos / vel / euler / body rates,
  * rr[4..5] = mass scale [lo,hi], rr[6..7] = inertia scale [lo,hi].
- * 16 uniforms of 16 bits = the two Philox blocks 2*ctr, 2*ctr+1 of subsequence
- * (stream<<48 | gid); u[2j] = low half, u[2j+1] = high half of word j.
+ * Philox block 2*ctr of subsequence (stream<<48 | gid) carries the 12 state
+ * uniforms, three per 32-bit word: bits 10..0 and 21..11 on the 11-bit lattice
+ * (h + 1/2) / 2048, bits 31..22 on the 10-bit lattice (h + 1/2) / 1024 -- word
+ * 0 position, 1 velocity, 2 euler angles, 3 body rates; block 2*ctr + 1 carries
+ * the 4 per-episode params as 16-bit uniforms (mass, Ixx = low / high half of
+ * word 0; Iyy, Izz = word 1).  (Round 3: the state draw was two blocks of 16-bit
+ * uniforms; the device makes this draw speculatively in every step.)
+ * u16[0..11] = the state uniforms, u16[12..15] = the params uniforms.
  * All arithmetic in binary32 with explicit fmaf so that HIP == CPU bit for bit
  * up to the euler2quat sin/cos (compared to tolerance). */
 void FN(qso_random_init)(uint64_t seed, uint64_t stream, uint64_t gid, uint64_t ctr,
@@ -580,7 +586,13 @@ void FN(qso_random_init)(uint64_t seed, uint64_t stream, uint64_t gid, uint64_t 
     int i;
     for (i = 0; i < 2; ++i)
         FN(qso_philox4x32_10)(seed, (stream << 48) | gid, 2ull * ctr + (uint64_t)i, w + 4 * i);
-    for (i = 0; i < 8; ++i) { u[2 * i] = u16f(w[i] & 0xFFFFu); u[2 * i + 1] = u16f(w[i] >> 16); }
+    for (i = 0; i < 4; ++i) {
+        u[3 * i + 0] = fmaf((float)(w[i] & 0x7FFu), 4.8828125e-04f, 2.44140625e-04f);
+        u[3 * i + 1] = fmaf((float)((w[i] >> 11) & 0x7FFu), 4.8828125e-04f, 2.44140625e-04f);
+        u[3 * i + 2] = fmaf((float)(w[i] >> 22), 9.765625e-04f, 4.8828125e-04f);
+    }
+    u[12] = u16f(w[4] & 0xFFFFu); u[13] = u16f(w[4] >> 16);
+    u[14] = u16f(w[5] & 0xFFFFu); u[15] = u16f(w[5] >> 16);
     if (u16) for (i = 0; i < 16; ++i) u16[i] = u[i];
     float e[3];
     for (i = 0; i < 13; ++i) { sc[i] = 0; st[i] = 0; }

@@ -457,6 +457,11 @@ __device__ __forceinline__ float sym(float u) { return __fmaf_rn(2.0f, u, -1.0f)
 // (0,1) uniform from 16 random bits, (h + 1/2) / 65536: exact in binary32
 __device__ __forceinline__ float u16lo(unsigned w) { return __fmaf_rn((float)(w & 0xFFFFu), 1.52587890625e-05f, 7.62939453125e-06f); }
 __device__ __forceinline__ float u16hi(unsigned w) { return __fmaf_rn((float)(w >> 16), 1.52587890625e-05f, 7.62939453125e-06f); }
+// three (0,1) uniforms from ONE 32-bit word: bits 10..0 and 21..11 on the 11-bit lattice (h + 1/2) / 2048, bits 31..22 on the
+// 10-bit lattice (h + 1/2) / 1024; exact in binary32
+__device__ __forceinline__ float u11a(unsigned w) { return __fmaf_rn((float)(w & 0x7FFu), 4.8828125e-04f, 2.44140625e-04f); }
+__device__ __forceinline__ float u11b(unsigned w) { return __fmaf_rn((float)((w >> 11) & 0x7FFu), 4.8828125e-04f, 2.44140625e-04f); }
+__device__ __forceinline__ float u10c(unsigned w) { return __fmaf_rn((float)(w >> 22), 9.765625e-04f, 4.8828125e-04f); }
 
 struct RandCfg {
     uint64_t seed;
@@ -472,16 +477,21 @@ __device__ __forceinline__ uint4 philox_block(uint64_t seed, uint64_t stream, ui
     return rocrand4(&rs);
 }
 
-// randomised initial state (+ per-episode params): 16 uniforms of 16 bits = the two Philox blocks
-// 2*ctr, 2*ctr+1 (a reset sits on the step's critical path; 16 bits resolve 0.5 m to 8 um).
-// u[2j] = low half, u[2j+1] = high half of word j.  Half-angles stay below pi/4 (qs_create checks
-// init_range[2] <= pi/2), so the reduction-free sincos applies.
-// Build extension; the reference's v0/v2 have no randomness.
+// Randomised initial state (+ per-episode params).  The draw of a possible reset sits in EVERY step of the step kernels (the
+// target wave makes it speculatively), so it is kept to what is needed (round 3: the state took two Philox blocks of 16-bit
+// uniforms before; a block is ~115 vector instructions, ~8 % of a step):
+//   block 2*ctr      the chaser's 12 state uniforms, three per word (u11a, u11b, u10c): word 0 position x,y,z; 1 velocity;
+//                    2 euler angles; 3 body rates -- 0.5 m resolved to 0.25-0.5 mm, 0.2 rad to 0.1-0.2 mrad;
+//   block 2*ctr + 1  ONLY with per-episode params (QS_RANDOMISE_PARAMS): mass, Ixx (low / high half of word 0), Iyy, Izz (word 1),
+//                    16-bit lattice.
+// Half-angles stay below pi/4 (qs_create checks init_range[2] <= pi/2), so the reduction-free sincos applies.
+// Build extension; the reference's v0/v2 have no randomness.  Pinned bit for bit in the oracle.
+template <bool WITH_PAR>
 __device__ __forceinline__ void random_init_words(const RandCfg &rc, uint64_t stream, uint64_t gid, uint64_t ctr,
                                                   uint4 &w0, uint4 &w1)
 {
     w0 = philox_block(rc.seed, stream, gid, 2ull * ctr + 0);
-    w1 = philox_block(rc.seed, stream, gid, 2ull * ctr + 1);
+    if (WITH_PAR) w1 = philox_block(rc.seed, stream, gid, 2ull * ctr + 1);
 }
 
 template <bool WITH_PAR>
@@ -489,28 +499,28 @@ __device__ __forceinline__ void random_init_apply(const RandCfg &rc, const uint4
                                                   float st[13], Par &P)
 {
     nominal_init(sc, st);
-    sc[0] = __fmaf_rn(sym(u16lo(w0.x)), rc.rr[0], 8.0f);
-    sc[1] = __fmaf_rn(sym(u16hi(w0.x)), rc.rr[0], -50.0f);
-    sc[2] = __fmaf_rn(sym(u16lo(w0.y)), rc.rr[0], 5.0f);
-    sc[3] = sym(u16hi(w0.y)) * rc.rr[1];
-    sc[4] = sym(u16lo(w0.z)) * rc.rr[1];
-    sc[5] = sym(u16hi(w0.z)) * rc.rr[1];
-    float e0 = sym(u16lo(w0.w)) * rc.rr[2];
-    float e1 = sym(u16hi(w0.w)) * rc.rr[2];
-    float e2 = sym(u16lo(w1.x)) * rc.rr[2];
+    sc[0] = __fmaf_rn(sym(u11a(w0.x)), rc.rr[0], 8.0f);
+    sc[1] = __fmaf_rn(sym(u11b(w0.x)), rc.rr[0], -50.0f);
+    sc[2] = __fmaf_rn(sym(u10c(w0.x)), rc.rr[0], 5.0f);
+    sc[3] = sym(u11a(w0.y)) * rc.rr[1];
+    sc[4] = sym(u11b(w0.y)) * rc.rr[1];
+    sc[5] = sym(u10c(w0.y)) * rc.rr[1];
+    float e0 = sym(u11a(w0.z)) * rc.rr[2];
+    float e1 = sym(u11b(w0.z)) * rc.rr[2];
+    float e2 = sym(u10c(w0.z)) * rc.rr[2];
     float sr, cr, sp, cp, sy, cy;
     q_sincos_small(0.5f * e0, sr, cr);
     q_sincos_small(0.5f * e1, sp, cp);
     q_sincos_small(0.5f * e2, sy, cy);
     euler2quat_trig(sr, cr, sp, cp, sy, cy, sc + 6);
-    sc[10] = sym(u16hi(w1.x)) * rc.rr[3];
-    sc[11] = sym(u16lo(w1.y)) * rc.rr[3];
-    sc[12] = sym(u16hi(w1.y)) * rc.rr[3];
+    sc[10] = sym(u11a(w0.w)) * rc.rr[3];
+    sc[11] = sym(u11b(w0.w)) * rc.rr[3];
+    sc[12] = sym(u10c(w0.w)) * rc.rr[3];
     if (WITH_PAR) {
-        P.m = rc.par_nom[0] * __fmaf_rn(rc.rr[5] - rc.rr[4], u16lo(w1.z), rc.rr[4]);
-        P.Ixx = rc.par_nom[1] * __fmaf_rn(rc.rr[7] - rc.rr[6], u16hi(w1.z), rc.rr[6]);
-        P.Iyy = rc.par_nom[2] * __fmaf_rn(rc.rr[7] - rc.rr[6], u16lo(w1.w), rc.rr[6]);
-        P.Izz = rc.par_nom[3] * __fmaf_rn(rc.rr[7] - rc.rr[6], u16hi(w1.w), rc.rr[6]);
+        P.m = rc.par_nom[0] * __fmaf_rn(rc.rr[5] - rc.rr[4], u16lo(w1.x), rc.rr[4]);
+        P.Ixx = rc.par_nom[1] * __fmaf_rn(rc.rr[7] - rc.rr[6], u16hi(w1.x), rc.rr[6]);
+        P.Iyy = rc.par_nom[2] * __fmaf_rn(rc.rr[7] - rc.rr[6], u16lo(w1.y), rc.rr[6]);
+        P.Izz = rc.par_nom[3] * __fmaf_rn(rc.rr[7] - rc.rr[6], u16hi(w1.y), rc.rr[6]);
     } else {
         P = Par{rc.par_nom[0], rc.par_nom[1], rc.par_nom[2], rc.par_nom[3]};
     }
@@ -520,8 +530,8 @@ template <bool WITH_PAR>
 __device__ __forceinline__ void random_init(const RandCfg &rc, uint64_t stream, uint64_t gid, uint64_t ctr,
                                             float sc[13], float st[13], Par &P)
 {
-    uint4 w0, w1;
-    random_init_words(rc, stream, gid, ctr, w0, w1);
+    uint4 w0, w1 = make_uint4(0, 0, 0, 0);
+    random_init_words<WITH_PAR>(rc, stream, gid, ctr, w0, w1);
     random_init_apply<WITH_PAR>(rc, w0, w1, sc, st, P);
 }
 

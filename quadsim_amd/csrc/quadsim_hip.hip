@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <dlfcn.h>
+#include <algorithm>
 #include <atomic>
 #include <condition_variable>
 #include <mutex>
@@ -134,15 +135,23 @@ namespace {
 #define QS_BLOCK 256
 #endif
 constexpr int kBlock = QS_BLOCK;  // 4 wavefronts = 4 tiles per workgroup
-// 1: the role-split step kernel's target wave prepares, every step, what a rocRAND reset of that step would install (state,
-// observation, per-episode parameters) in LDS, and the chaser wave's reset branch is a copy; 0 (default): the target wave
-// hands over the Philox words, the chaser wave expands them inside its branch.  Bit-identical either way.  Measured (round 3,
-// profiles/r03/ab_experiments.txt section J): 1 is SLOWER, 5.27 vs 4.72 us per step on two private queues, 7.0 vs 6.6 us on
-// the HIP stream -- every SIMD hosts one chaser and one target wave (tools/wave_map3.hip), so the target wave's time is not
-// free: the branch runs in 4 chaser waves of 5, the preparation in 5 target waves of 5, plus the LDS traffic.
-#ifndef QS_RESET_PREP
-#define QS_RESET_PREP 0
+// Where the rocRAND reset of a step is prepared in the role-split step kernel -- template parameter PREP of k_env_split, chosen
+// per launch by the host (bit-identical either way):
+//   0  the target wave hands over the Philox words, the chaser wave expands them inside its reset branch (0.6 us of its critical
+//      path in 4 workgroups of 5: >= 1 of 64 lanes resets);
+//   2  a THIRD wave per workgroup does the draw and the preparation (state, its observation, per-episode params -> LDS), every
+//      step, and touches nothing else: the chaser wave's branch is a 25-word LDS copy and the target wave draws nothing.  Every
+//      SIMD hosts one wave of each role (tools/wave_map3.hip) at less than half of its issue rate, so the third wave's ~370
+//      instructions run beside the others: 65 536 envs 5.05 -> 4.71 us per step (one private queue), 4.6 -> 4.05 us (two),
+//      HIP stream 6.6 -> 6.25 us; 32 768 envs 4.31 -> 3.76 us.
+//   (1, the TARGET wave preparing it, was measured slower -- it becomes the long pole at barrier #2 -- and is gone.)
+// The third wave needs residency: 112 VGPRs allow 4 waves per SIMD, i.e. 4 096 waves on the chip; a launch whose tiles x 3 waves
+// exceed that runs its workgroups in two rounds (131 072 envs in ONE launch: 8.9 -> 10.7 us), so PREP = 2 is used up to
+// kPrepMaxTiles tiles per launch (QS_RESET_PREP=0/2 forces one; profiles/r03/ab_experiments.txt section J).
+#ifndef QS_PREP_MAX_TILES
+#define QS_PREP_MAX_TILES 1365
 #endif
+constexpr int64_t kPrepMaxTiles = QS_PREP_MAX_TILES;
 #ifndef QS_SPLIT_MAX_ENVS
 #define QS_SPLIT_MAX_ENVS 131072
 #endif
@@ -431,20 +440,20 @@ __global__ __launch_bounds__(kBlock) void k_env(StepArgs A)
 // instruction streams run in the time of one.  Hand-overs through 7.5 KiB of LDS, two workgroup barriers per step:
 //   target wave:  advance target | draw Philox words  -> #1 ->  PID, limit new control            -> #2 -> apply reset
 //   chaser wave:  mix, advance chaser                 -> #1 ->  state2rel, reward, done -> flag  -> #2 -> reset, stores
-template <int INTEG, bool PARAMS, int RMODE>
-__global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
+// waves per workgroup of k_env_split: with PREP == 2 the rocRAND reset modes get a third wave
+constexpr int split_waves(int rmode, int prep) { return (prep == 2 && (rmode == 1 || rmode == 2)) ? 3 : 2; }
+
+template <int INTEG, bool PARAMS, int RMODE, int PREP>
+__global__ __launch_bounds__(3 * kTile) void k_env_split(StepArgs A)
 {
     __shared__ float s_tgt[13][kTile];
-#if QS_RESET_PREP
-    // [step parity][chaser reset state 13 | its observation 12 | per-episode params 4][lane]: what a reset of THIS step would
-    // install, prepared by the target wave every step off the chaser wave's critical path (the chaser wave reads step t's block
-    // while the target wave, running ahead in a roll-out, fills t+1's)
-    constexpr bool kPrep = RMODE == 1 || RMODE == 2;
-    __shared__ float s_rst[kPrep ? 2 : 1][kPrep ? 29 : 1][kTile];
-#else
-    constexpr bool kPrep = false;
-    __shared__ uint4 s_phx[2][2][kTile];          // [step parity][block]: the chaser wave reads step t's words while t+1's are drawn
-#endif
+    // PREP == 2: [chaser reset state 13 | its observation 12 | per-episode params 4][lane]: what a reset of THIS step would
+    // install, prepared every step off the chaser wave's critical path.  One buffer suffices in a roll-out too: it is written
+    // between barriers #1 and #2 of a step and read behind #2; the next write is behind the NEXT step's #1, which the readers
+    // have passed.  PREP == 0: [step parity][block]: the chaser wave reads step t's Philox words while t+1's are drawn.
+    constexpr bool kPrep = PREP == 2 && (RMODE == 1 || RMODE == 2);
+    __shared__ float s_rst[kPrep ? 29 : 1][kTile];
+    __shared__ uint4 s_phx[kPrep ? 1 : 2][kPrep ? 1 : 2][kTile];
     __shared__ unsigned char s_done[kTile], s_limt[kTile];
     const int lane = threadIdx.x & (kTile - 1);
     const int role = threadIdx.x >> 6;
@@ -536,20 +545,20 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
                     for (int i = 0; i < 13; ++i) { ic[i] = src[i]; it[i] = src[13 + i]; }
                     rel_obs<false>(ic, it, obs);
                 } else {
-#if QS_RESET_PREP
-                    // the reset state, its observation and the episode's parameters were prepared by the target wave: a copy
+                    if (kPrep) {
+                        // the reset state, its observation and the episode's parameters were prepared by the third wave: a copy
 #pragma unroll
-                    for (int i = 0; i < 13; ++i) ic[i] = s_rst[t & 1][i][lane];
+                        for (int i = 0; i < 13; ++i) ic[i] = s_rst[i][lane];
 #pragma unroll
-                    for (int i = 0; i < 12; ++i) obs[i] = s_rst[t & 1][13 + i][lane];
-                    if (PARAMS && RMODE == 2) P = Par{s_rst[t & 1][25][lane], s_rst[t & 1][26][lane], s_rst[t & 1][27][lane], s_rst[t & 1][28][lane]};
-#else
-                    const uint4 w0 = s_phx[t & 1][0][lane], w1 = s_phx[t & 1][1][lane];
-                    Par Pn;
-                    random_init_apply<RMODE == 2>(A.rc, w0, w1, ic, it, Pn);
-                    if (PARAMS && RMODE == 2) P = Pn;
-                    rel_obs<true>(ic, it, obs);
-#endif
+                        for (int i = 0; i < 12; ++i) obs[i] = s_rst[13 + i][lane];
+                        if (PARAMS && RMODE == 2) P = Par{s_rst[25][lane], s_rst[26][lane], s_rst[27][lane], s_rst[28][lane]};
+                    } else {
+                        const uint4 w0 = s_phx[t & 1][0][lane], w1 = RMODE == 2 ? s_phx[t & 1][1][lane] : make_uint4(0, 0, 0, 0);
+                        Par Pn;
+                        random_init_apply<RMODE == 2>(A.rc, w0, w1, ic, it, Pn);
+                        if (PARAMS && RMODE == 2) P = Pn;
+                        rel_obs<true>(ic, it, obs);
+                    }
                 }
 #pragma unroll
                 for (int i = 0; i < 13; ++i) sc[i] = ic[i];
@@ -588,7 +597,7 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
 #endif
         QS_STAMP_AT(7);
         QS_STAMP_FLUSH();
-    } else {
+    } else if (role == 1) {
         float st[13], ut[4], qd[4];
 #pragma unroll
         for (int i = 0; i < 13; ++i) st[i] = b[(F_ST + i) * kTile];
@@ -617,34 +626,15 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
             s_limt[lane] = lim_t ? 1 : 0;
             uint4 w0 = make_uint4(0, 0, 0, 0), w1 = w0;
             Par Pn = P;
-            if (RMODE == 1 || RMODE == 2) {
-                random_init_words(A.rc, STREAM_AUTORESET, A.gid0 + (uint64_t)env, k + 1, w0, w1);
-#if !QS_RESET_PREP
+            if ((RMODE == 1 || RMODE == 2) && !kPrep) {
+                random_init_words<RMODE == 2>(A.rc, STREAM_AUTORESET, A.gid0 + (uint64_t)env, k + 1, w0, w1);
                 s_phx[t & 1][0][lane] = w0;
-                s_phx[t & 1][1][lane] = w1;
-#endif
+                if (RMODE == 2) s_phx[t & 1][1][lane] = w1;     // the params block: only drawn with per-episode params
             }
             QS_STAMP_AT(2);
             __syncthreads();                                              // #1
             QS_STAMP_AT(3);
             if (A.T == 1) __builtin_amdgcn_s_setprio(0);
-#if QS_RESET_PREP
-            if (kPrep) {
-                // what a reset of this step would install (random_init_apply + state2rel of it: the same device functions the
-                // serial kernel runs inside its reset branch, so the same bits), computed for EVERY lane while the chaser wave
-                // evaluates state2rel and the reward; needed only after #2
-                float ic[13], it_[13], robs[12];
-                random_init_apply<RMODE == 2>(A.rc, w0, w1, ic, it_, Pn);
-                rel_obs<true>(ic, it_, robs);
-#pragma unroll
-                for (int i = 0; i < 13; ++i) s_rst[t & 1][i][lane] = ic[i];
-#pragma unroll
-                for (int i = 0; i < 12; ++i) s_rst[t & 1][13 + i][lane] = robs[i];
-                if (PARAMS && RMODE == 2) {
-                    s_rst[t & 1][25][lane] = Pn.m; s_rst[t & 1][26][lane] = Pn.Ixx; s_rst[t & 1][27][lane] = Pn.Iyy; s_rst[t & 1][28][lane] = Pn.Izz;
-                }
-            }
-#endif
             float u_t[4];
             target_control(A.C.kind, pdes, vdes, qd, 0.0f, pre, dv, P.m, u_t);   // from the state BEFORE stepping
             u_limit(u_t, P.m * kG, ut);
@@ -665,10 +655,12 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
                 } else {
                     nominal_init(ic, it);
                     if (PARAMS && RMODE == 2) {
-#if !QS_RESET_PREP
-                        random_init_apply<true>(A.rc, w0, w1, ic, it, Pn);
-                        nominal_init(ic, it);
-#endif
+                        if (kPrep) {
+                            Pn = Par{s_rst[25][lane], s_rst[26][lane], s_rst[27][lane], s_rst[28][lane]};
+                        } else {
+                            random_init_apply<true>(A.rc, w0, w1, ic, it, Pn);
+                            nominal_init(ic, it);
+                        }
                         P = Pn;
                     }
                 }
@@ -688,6 +680,31 @@ __global__ __launch_bounds__(2 * kTile) void k_env_split(StepArgs A)
         }
         QS_STAMP_AT(6);
         QS_STAMP_FLUSH();
+    }
+    else if (kPrep) {
+        // third wave (rocRAND reset modes only): what a reset of each step would install -- the draw, random_init_apply and the
+        // state2rel of the result: the same device functions the serial kernel runs inside its reset branch, so the same bits --
+        // for EVERY lane, into LDS; it touches no global memory but the step counter and joins both barriers of every step.  The
+        // chaser wave's reset branch is a 25-word copy, the target wave draws nothing.
+#pragma clang loop unroll(disable)
+        for (int64_t t = 0; t < A.T; ++t) {
+            const uint64_t k = k0 + (uint64_t)t;
+            uint4 w0, w1 = make_uint4(0, 0, 0, 0);
+            random_init_words<RMODE == 2>(A.rc, STREAM_AUTORESET, A.gid0 + (uint64_t)env, k + 1, w0, w1);
+            __syncthreads();                                              // #1
+            float ic[13], it_[13], robs[12];
+            Par Pn;
+            random_init_apply<RMODE == 2>(A.rc, w0, w1, ic, it_, Pn);
+            rel_obs<true>(ic, it_, robs);
+#pragma unroll
+            for (int i = 0; i < 13; ++i) s_rst[i][lane] = ic[i];
+#pragma unroll
+            for (int i = 0; i < 12; ++i) s_rst[13 + i][lane] = robs[i];
+            if (PARAMS && RMODE == 2) {
+                s_rst[25][lane] = Pn.m; s_rst[26][lane] = Pn.Ixx; s_rst[27][lane] = Pn.Iyy; s_rst[28][lane] = Pn.Izz;
+            }
+            __syncthreads();                                              // #2
+        }
     }
 }
 
@@ -1634,6 +1651,15 @@ struct Bounce {
     }
 };
 
+// reset-preparation variant of the role-split kernel for a launch of `tiles` tiles (see kPrepMaxTiles)
+int prep_for(int rmode, int64_t tiles)
+{
+    static const int forced = getenv("QS_RESET_PREP") ? atoi(getenv("QS_RESET_PREP")) : -1;
+    if (rmode != 1 && rmode != 2) return 0;
+    if (forced == 0 || forced == 2) return forced;
+    return tiles <= kPrepMaxTiles ? 2 : 0;
+}
+
 template <int INTEG, bool PARAMS, int RMODE>
 void launch_one(hipStream_t s, const StepArgs &A)
 {
@@ -1644,7 +1670,9 @@ void launch_one(hipStream_t s, const StepArgs &A)
     static const int forced = getenv("QS_SPLIT") ? atoi(getenv("QS_SPLIT")) : -1;
     const bool split = forced >= 0 ? forced != 0 : A.n <= kSplitMaxEnvs;
     const int64_t tiles = A.tile_end - A.tile0;
-    if (split) hipLaunchKernelGGL((k_env_split<INTEG, PARAMS, RMODE>), dim3((unsigned)tiles), dim3(2 * kTile), 0, s, A);
+    if (split && prep_for(RMODE, tiles) == 2 && (RMODE == 1 || RMODE == 2))
+        hipLaunchKernelGGL((k_env_split<INTEG, PARAMS, RMODE, (RMODE == 1 || RMODE == 2) ? 2 : 0>), dim3((unsigned)tiles), dim3(3 * kTile), 0, s, A);
+    else if (split) hipLaunchKernelGGL((k_env_split<INTEG, PARAMS, RMODE, 0>), dim3((unsigned)tiles), dim3(2 * kTile), 0, s, A);
     else hipLaunchKernelGGL((k_env<INTEG, PARAMS, RMODE>), dim3((unsigned)((tiles + kBlock / kTile - 1) / (kBlock / kTile))), dim3(kBlock), 0, s, A);
 }
 
@@ -1879,7 +1907,7 @@ struct QsChain {
     bool have_exe = false, have_reader = false;
     std::vector<char> image;          // the gfx950 code object (kept alive for the executable)
     uint64_t kernel_object = 0;
-    int v_integ = -1, v_params = -1, v_rmode = -1, v_split = -1;   // the instantiation kernel_object belongs to
+    int v_integ = -1, v_params = -1, v_rmode = -1, v_split = -1, v_prep = -1;   // the instantiation kernel_object belongs to
     uint32_t kernarg_size = 0, group_size = 0, private_size = 0;
     unsigned block = 0;
     size_t stride = 0, slots = 0;
@@ -2049,10 +2077,14 @@ int chain_resolve_kernel(QsEnv *e)
     const int params = (rmode == 2 || e->per_env_params) ? 1 : 0;
     static const int forced = getenv("QS_SPLIT") ? atoi(getenv("QS_SPLIT")) : -1;
     const int split = (forced >= 0 ? forced != 0 : e->n <= kSplitMaxEnvs) ? 1 : 0;
-    if (c->kernel_object && integ == c->v_integ && rmode == c->v_rmode && params == c->v_params && split == c->v_split) return QS_OK;
+    int64_t lane_tiles = 0;
+    for (const QsChainLane &L : c->lanes) lane_tiles = std::max<int64_t>(lane_tiles, L.tile_end - L.tile0);
+    if (c->lanes.empty()) lane_tiles = e->tiles;          // chain_open resolves once before the lanes exist: re-resolved at the first step
+    const int prep = split ? prep_for(rmode, lane_tiles) : 0;
+    if (c->kernel_object && integ == c->v_integ && rmode == c->v_rmode && params == c->v_params && split == c->v_split && prep == c->v_prep) return QS_OK;
     char sym[160];
-    snprintf(sym, sizeof sym, split ? "_ZN12_GLOBAL__N_111k_env_splitILi%dELb%dELi%dEEEvNS_8StepArgsE.kd"
-                                    : "_ZN12_GLOBAL__N_15k_envILi%dELb%dELi%dEEEvNS_8StepArgsE.kd", integ, params, rmode);
+    if (split) snprintf(sym, sizeof sym, "_ZN12_GLOBAL__N_111k_env_splitILi%dELb%dELi%dELi%dEEEvNS_8StepArgsE.kd", integ, params, rmode, prep);
+    else snprintf(sym, sizeof sym, "_ZN12_GLOBAL__N_15k_envILi%dELb%dELi%dEEEvNS_8StepArgsE.kd", integ, params, rmode);
     hsa_executable_symbol_t ks;
     uint64_t ko = 0;
     uint32_t ka = 0, gs = 0, ps = 0;
@@ -2065,8 +2097,8 @@ int chain_resolve_kernel(QsEnv *e)
     if (c->stride && (((size_t)ka + 255) & ~size_t(255)) > c->stride)
         return fail(QS_ERR_HIP, "queue mode: kernel argument block of %s (%u B) exceeds the ring's slot size", sym, ka);
     c->kernel_object = ko; c->kernarg_size = ka; c->group_size = gs; c->private_size = ps;
-    c->block = split ? 2 * kTile : kBlock;
-    c->v_integ = integ; c->v_rmode = rmode; c->v_params = params; c->v_split = split;
+    c->block = split ? split_waves(rmode, prep) * kTile : kBlock;
+    c->v_integ = integ; c->v_rmode = rmode; c->v_params = params; c->v_split = split; c->v_prep = prep;
     return QS_OK;
 }
 
@@ -2316,7 +2348,7 @@ int chain_submit(QsEnv *e, const StepArgs *steps, int64_t T)
         for (size_t q = 0; q < nl; ++q) {
             QsChainLane &L = c->lanes[q];
             const int64_t tiles = L.tile_end - L.tile0;
-            const unsigned grid = c->block == 2 * kTile ? (unsigned)(tiles * c->block)
+            const unsigned grid = c->v_split ? (unsigned)(tiles * c->block)
                                                         : (unsigned)(((tiles + kBlock / kTile - 1) / (kBlock / kTile)) * kBlock);
             // stream-ordered: the LAST packet of the submission publishes -- agent-scope release (the outputs of all T steps leave
             // the L2s; the state lines are written back too but stay valid where they are) and the completion signal the

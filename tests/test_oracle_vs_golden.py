@@ -166,7 +166,25 @@ def test_random_init_ranges(oracle64):
         assert 0.8 * 0.18 <= par[0] <= 1.2 * 0.18 * (1 + 1e-6)
     U = np.array(U)
     assert U.min() > 0 and U.max() < 1 and abs(U.mean() - 0.5) < 0.02 and abs(U.var() - 1 / 12) < 0.01
-    assert np.all(U * 65536 - 0.5 == np.round(U * 65536 - 0.5))        # 16-bit lattice (h + 1/2) / 65536
+    # lattices: three state uniforms per Philox word (11, 11 and 10 bits), the four params uniforms on 16 bits
+    bits = np.array([11, 11, 10] * 4 + [16] * 4)
+    scaled = U * (2.0 ** bits) - 0.5
+    assert np.all(scaled == np.round(scaled)) and np.all(scaled >= 0) and np.all(scaled < 2.0 ** bits)
+    # every field of every word is used and independent enough to be uniform on its own
+    for j in range(16):
+        assert abs(U[:, j].mean() - 0.5) < 0.06, j
+    # the state uniforms come from block 2*ctr alone, the params from block 2*ctr + 1 alone
+    w0 = oracle64.philox(1234, (0 << 48) | 17, 2 * 7)
+    w1 = oracle64.philox(1234, (0 << 48) | 17, 2 * 7 + 1)
+    _, _, _, u = oracle64.random_init(1234, 0, 17, 7, rr)
+    want = []
+    for w in w0:
+        w = int(w)
+        want += [((w & 0x7FF) + 0.5) / 2048.0, (((w >> 11) & 0x7FF) + 0.5) / 2048.0, ((w >> 22) + 0.5) / 1024.0]
+    for w in w1[:2]:
+        w = int(w)
+        want += [((w & 0xFFFF) + 0.5) / 65536.0, ((w >> 16) + 0.5) / 65536.0]
+    np.testing.assert_array_equal(u, np.array(want, np.float32))
 
 
 # ---------------------------------------------------------------- section 8f-2: docking-v1, hovering-v0
