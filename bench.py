@@ -586,7 +586,7 @@ def main():
         groups = env.set_groups(groups, threads=bool(args.group_threads))
     P = max(1, min(args.action_pool, K * R, (1 << 29) // (n * 16)))      # at most 512 MiB of action batches
     pool = env.random_actions(P, step0=0)               # [P,N,4] U(-1,1), resident in HBM before timing
-    queue_mode, queues, queue_note = pick_launch_path(env, lambda: make_env(args.integrator), pool, max(200, min(1000, K)))
+    queue_mode, queues, queue_note = pick_launch_path(env, lambda: make_env(args.integrator), pool, 1000)
     try:
         runs = [time_steps(env, K, R, W, pool, groups) for _ in range(max(1, args.repeats))]
         guard = None
@@ -660,7 +660,8 @@ def main():
                    "parallelism": "env-sharded x%d, no data-path collective" % world},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                     "kernel": ("k_env_split<%s> (T=1): two waves per tile" if split else "k_env<%s> (T=1)") % args.integrator
+                     "kernel": ("k_env_split<%s> (T=1): chaser wave + target wave + reset-preparation wave per tile (two waves where "
+                                "the reset is not rocRAND's or the launch exceeds 1 365 tiles)" if split else "k_env<%s> (T=1)") % args.integrator
                                + (", dispatched from the handle's private AQL queue" if queue_mode == "private" else ""),
                      "bytes_per_env_step": bpe, "bytes_per_step": bpe * n, "launches_per_step": max(groups, queues, 1),
                      "step_period_us": step_us,
@@ -684,10 +685,11 @@ def main():
             out["roofline"].update({"stamp_period_us": st["stamp_period_us"], "stamp_kernel_span_us": st["stamp_kernel_span_us"],
                                     "stamp_gap_us": st["stamp_gap_us"], "stamp_frac": frac_of(st["stamp_period_us"]),
                                     "stamp_source": os.path.relpath(sp, ROOT),
-                                    "stamp_note": "light stamped build (-DQS_STAMP=2: first / last s_memrealtime of each wave), %s, %d-batch "
-                                                  "action pool; period = first workgroup start -> next step's first start, span = first start "
-                                                  "-> last wave drained" % ("%d private queue(s)" % st["queues"] if st.get("queues") else "HIP stream",
-                                                                            st.get("action_pool", 0))})
+                                    "stamp_note": "light stamped build (-DQS_STAMP=2: one workgroup in 64 records the first / last "
+                                                  "s_memrealtime of its waves; steps within 1-3 %% of the product build), %s, %d-batch action "
+                                                  "pool; period = consecutive starts of the same workgroups (the chain's own); span / gap are "
+                                                  "approximate (span ends at 'stores issued' of the sampled workgroups)"
+                                                  % ("%d private queue(s)" % st["queues"] if st.get("queues") else "HIP stream", st.get("action_pool", 0))})
         except (OSError, KeyError, ValueError):
             pass
     # (2) rocprofv3 kernel averages of the committed profiles: per-launch duration of the step kernel, with the bytes of ONE
