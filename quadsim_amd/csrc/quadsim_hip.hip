@@ -1652,9 +1652,15 @@ struct Bounce {
 };
 
 // reset-preparation variant of the role-split kernel for a launch of `tiles` tiles (see kPrepMaxTiles)
+std::atomic<int> &prep_forced()
+{
+    static std::atomic<int> f{getenv("QS_RESET_PREP") ? atoi(getenv("QS_RESET_PREP")) : -1};
+    return f;
+}
+
 int prep_for(int rmode, int64_t tiles)
 {
-    static const int forced = getenv("QS_RESET_PREP") ? atoi(getenv("QS_RESET_PREP")) : -1;
+    const int forced = prep_forced().load(std::memory_order_relaxed);
     if (rmode != 1 && rmode != 2) return 0;
     if (forced == 0 || forced == 2) return forced;
     return tiles <= kPrepMaxTiles ? 2 : 0;
@@ -3397,6 +3403,11 @@ int qs_debug_chain_poison_owner(QsEnv *e)
     e->chain->hip_dirty = false;          // keep the poisoned owners: the next step must not reset them
     return QS_OK;
 }
+
+// Diagnostic (not in quadsim.h; tests and A/B tools only): force the reset-preparation variant of the role-split step kernel for
+// every later launch of the process: 0 two waves, 2 three waves, -1 the default choice by tiles per launch.  Returns the previous
+// setting.  (Same results bit for bit: tests/test_gpu_groups_and_rollout.py::test_reset_preparation_wave_is_bit_identical.)
+int qs_debug_set_reset_prep(int mode) { return prep_forced().exchange((mode == 0 || mode == 2) ? mode : -1); }
 
 // Diagnostic (not in quadsim.h; tests only): the NEXT private-queue step runs with workgroup b stepping tile b + shift of its
 // launch -- every tile on another XCD than the one that holds its state -- without any synchronisation in between: the

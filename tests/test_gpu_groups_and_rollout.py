@@ -614,6 +614,55 @@ def test_threaded_group_step_is_on_its_stream_when_the_call_returns(qa, torch):
     a.close(); b.close()
 
 
+@pytest.mark.parametrize("n,env_id,rnd,integ", [(65536, "docking-v0", 1, "frozen"), (64 * 37 + 11, "docking-v2", 2, "frozen"),
+                                                 (4096, "docking-v0", 2, "rk4"), (131072, "docking-v2", 2, "frozen")])
+def test_reset_preparation_wave_is_bit_identical(qa, torch, n, env_id, rnd, integ):
+    """k_env_split<.., PREP = 2> (round 3: a third wave per workgroup prepares what a rocRAND reset of the step would install, the
+    chaser wave copies it) against PREP = 0 (the chaser wave expands the Philox words inside its reset branch): every output of
+    every step, terminal rows, final state and per-episode params, single steps and a fused roll-out, HIP stream and private queues"""
+    lib = qa._lib.load()
+    lib.qs_debug_set_reset_prep.argtypes = [C.c_int]
+    kw = dict(num_envs=n, randomise=rnd, seed=31, init_range=qa.C3_INIT_RANGE, mass_scale=(0.8, 1.2), inertia_scale=(0.8, 1.2),
+              integrator=integ, copy=False)
+    res = []
+    try:
+        for prep in (0, 2):
+            lib.qs_debug_set_reset_prep(prep)
+            env = qa.VecDockingEnv(env_id, **kw)
+            env.reset()
+            t0 = np.zeros(n, np.float32); t0[::4] = 585.0
+            env.set_state(t=t0)
+            acts = env.random_actions(48, step0=0)
+            rec, n_done = [], 0
+            for k in range(24):
+                o, r, d, _ = env.step(acts[k])
+                rec.append((o.clone(), r.clone(), d.clone(), env._flags.clone(), env._term.clone(), env._tstate.clone()))
+                n_done += int(d.sum())
+            env.set_queue_mode(True, 2)
+            for k in range(24, 32):
+                o, r, d, _ = env.step(acts[k])
+                rec.append((o.clone(), r.clone(), d.clone(), env._flags.clone(), env._term.clone(), env._tstate.clone()))
+            env.set_queue_mode(False)
+            O, R, D, F = env.rollout(acts[32:48])
+            st = _full_state(env)
+            par = env.get_params() if rnd == 2 else None
+            res.append((rec, (O.clone(), R.clone(), D.clone(), F.clone()), st, par, env.step_counter, n_done))
+            env.close()
+    finally:
+        lib.qs_debug_set_reset_prep(-1)
+    a, b = res
+    assert a[5] >= n // 5 and a[4] == b[4] == 48
+    for k, (x, y) in enumerate(zip(a[0], b[0])):
+        d = x[2].bool()
+        assert torch.equal(x[0], y[0]) and torch.equal(x[1], y[1]) and torch.equal(x[2], y[2]) and torch.equal(x[3], y[3]), k
+        if bool(d.any()):
+            assert torch.equal(x[4][d], y[4][d]) and torch.equal(x[5][d], y[5][d]), k
+    assert all(torch.equal(u, v) for u, v in zip(a[1], b[1]))
+    np.testing.assert_array_equal(a[2], b[2])
+    if rnd == 2:
+        np.testing.assert_array_equal(a[3][0], b[3][0]); np.testing.assert_array_equal(a[3][1], b[3][1])
+
+
 def test_runner_role_split_kernel_is_bit_identical_to_one_wave_per_tile(qa):
     """k_runner_split (matrix waves + env waves, the default) against k_runner_rollout (one wave per tile) on the same envs:
     every output array and the final env state bit for bit -- exact-f32 and split-bf16 heads, plain and squashed policy,
