@@ -170,6 +170,7 @@ struct StepArgs {
     float *slab;           // nullable: packed roll-out slab [T,N,14] = obs 12, reward, done (as 0/1); replaces obs/reward/done
     int64_t n;
     int64_t tile0, tile_end;   // tiles [tile0, tile_end) are stepped by this launch (an env group; the whole handle by default)
+    int64_t dbg_shift;         // diagnostic (tests): workgroup b steps tile (b + dbg_shift) % tiles of its launch, i.e. on ANOTHER XCD
     int64_t io_env0, io_n;     // the I/O arrays start at env io_env0 and hold io_n envs per step (0, n: full-batch arrays)
     int64_t T;             // rollout length (1 for step)
     uint64_t step_idx;     // explicit step index (k_fill_actions); the env kernels read the device counter below
@@ -188,7 +189,6 @@ struct StepArgs {
                            // written and read with agent-scope atomics ONLY: like the state it guards, a plainly stored owner
                            // would stay dirty in the writing XCD's L2 and a misplaced workgroup would never see it
     unsigned *err;         // device word: bit 0 set when a workgroup found its tile owned by another XCD (it then touches nothing)
-    int dbg_shift;         // diagnostic (tests): workgroup b steps tile (b + dbg_shift) % tiles of its launch, i.e. on ANOTHER XCD
     unsigned long long *stamps;        // QS_STAMP builds: in-kernel timeline buffer (qs_debug_set_stamps), else nullptr
     unsigned long long stamp_cap, stamp_tiles;
 };
@@ -266,6 +266,16 @@ __device__ __forceinline__ void store_obs_cached(float *__restrict__ obs, int64_
 // a wave reads its own word at the start and writes k + T back at the end, so no workgroup ever waits for or
 // races with another one.  (A single shared word updated through a per-workgroup ticket cost 2 us per launch.)
 __device__ __forceinline__ uint64_t step_counter_begin(const StepArgs &A, int64_t tile) { return A.ctr[tile]; }
+// The single-step kernels request the word through the vector memory path (the zero below hides the wave-uniform address from
+// the compiler): as a scalar load it shared one counter -- and one wait -- with the kernel-argument fetch in front of the state
+// loads, i.e. an L2 round trip on every wave's critical path; as a vector load it is one more load beside the state's
+// (nominal-reset kernel 4.87 -> 4.74 us per step, two queues 4.41 -> 4.16; section J15)
+__device__ __forceinline__ uint64_t step_counter_begin_vmem(const StepArgs &A, int64_t tile)
+{
+    int zero;
+    asm("v_mov_b32 %0, 0" : "=v"(zero));
+    return A.ctr[tile + zero];
+}
 __device__ __forceinline__ void step_counter_end(const StepArgs &A, int64_t tile, int lane, uint64_t k)
 {
     if (lane == 0) A.ctr[tile] = k + (uint64_t)A.T;
@@ -279,7 +289,11 @@ __device__ __forceinline__ void step_counter_end(const StepArgs &A, int64_t tile
 constexpr unsigned kUnowned = 0xffffffffu;
 __device__ __forceinline__ unsigned chain_owner_request(const StepArgs &A, int64_t tile)
 {
-    return A.owner ? __hip_atomic_load(&A.owner[tile], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : kUnowned;
+    // no control flow around the load (an ordinary launch reads a word of its own step counter instead and ignores it): a
+    // load inside a branch is issued late and waited for at the branch's end (section J15)
+    const unsigned *p = A.owner ? A.owner + tile : reinterpret_cast<const unsigned *>(A.ctr + tile);
+    const unsigned v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return A.owner ? v : kUnowned;
 }
 
 // the check for a caller that requested the owner word earlier (no load latency on its critical path)
@@ -311,14 +325,15 @@ __device__ __forceinline__ bool chain_tile_misplaced(const StepArgs &A, int64_t 
     return chain_owner_mismatch(A, tile, lane, chain_owner_request(A, tile));
 }
 
-// tile of workgroup-local index b (0 <= b < the launch's tile count); dbg_shift != 0 only in the placement-guard test
+// tile of workgroup-local index b (0 <= b < the launch's tile count); dbg_shift != 0 only in the placement-guard test.
+// Branch-free on purpose, with dbg_shift next to tile0 / tile_end in StepArgs: a branch on a kernel argument at the very top of
+// the kernel made the compiler fetch that argument, wait, and only then fetch the rest -- a second scalar-memory round trip in
+// front of every wave's loads (+0.3 us per step; profiles/r03/ab_experiments.txt section J15).
 __device__ __forceinline__ int64_t launch_tile(const StepArgs &A, int64_t b)
 {
-    if (A.dbg_shift) {
-        const int64_t nt = A.tile_end - A.tile0;
-        b += A.dbg_shift;
-        if (b >= nt) b -= nt;
-    }
+    const int64_t nt = A.tile_end - A.tile0;
+    b += A.dbg_shift;
+    b -= (b >= nt) ? nt : 0;
     return A.tile0 + b;
 }
 
@@ -390,7 +405,7 @@ __global__ __launch_bounds__(kBlock) void k_env(StepArgs A)
     if (chain_tile_misplaced(A, tile, lane)) return;
     const int64_t io = env - A.io_env0;          // row of this env in the I/O arrays
     QS_ASSERT(io >= 0 && io < A.io_n);
-    const uint64_t k0 = step_counter_begin(A, tile);
+    const uint64_t k0 = step_counter_begin_vmem(A, tile);
     // the first action is requested together with the tile (one exposed memory latency per launch, not two) and
     // every later one a whole step ahead of its use
     float4 av_next = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
@@ -465,7 +480,7 @@ __global__ __launch_bounds__(3 * kTile) void k_env_split(StepArgs A)
     // private-queue launches: the tile's owning XCD is requested here and examined only after the first compute phase (below),
     // so that the check costs no memory latency; a misplaced workgroup computes on whatever it loaded and stores nothing
     const unsigned owner_xcc = chain_owner_request(A, tile);
-    const uint64_t k0 = step_counter_begin(A, tile);
+    const uint64_t k0 = step_counter_begin_vmem(A, tile);
     QS_STAMP_DECL;
     QS_STAMP_AT(0);
     const float *b = A.st + tile * (int64_t)(kRecWords * kTile) + lane;
