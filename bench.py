@@ -870,6 +870,22 @@ def extras(args, out, env, pool, make_env, time_steps, verify_private_queue, bar
                 pb["private_stream_ordered"]["env_step_alone_us"] = ws / 500 * 1e6
             except qa.QuadsimError as ex:
                 pb["private_stream_ordered"] = {"invalid": "the placement guard fired during this leg: %s" % ex}
+        # the same loop with the shipped actor INSIDE the launch: VecDockingEnv.step_policy = qs_policy_rollout(T = 1), one launch
+        # per step on the HIP stream, outputs consumable per step
+        env.set_queue_mode(False)
+        for prec in ("f32", "bf16x3"):
+            env.reset()
+            for _ in range(30):
+                env.step_policy(pol, precision=prec)
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(300):
+                env.step_policy(pol, precision=prec)
+            torch.cuda.synchronize()
+            wp = max_over_ranks(time.perf_counter() - t0) / 300
+            pb["one_launch_per_step_" + prec] = {"us_per_step": wp * 1e6, "value": total_envs / wp, "unit": "env-steps/s"}
+        pb["one_launch_per_step_what"] = ("VecDockingEnv.step_policy(policy): the actor on the matrix cores (exact-f32 MFMA / split-bf16 "
+                                          "operands) and the env step in ONE launch per step, outputs consumable per step")
         pb["what"] = ("VecDockingEnv.step(MlpPolicy.predict(obs)) per step, 300 steps; the policy is three torch GEMMs and dominates "
                       "both; per-step consumable outputs cost a release per step in either path, so the private queue buys nothing "
                       "here (DESIGN.md section 4a): use the HIP-stream mode for per-step loops, the fused qs_policy_rollout / "

@@ -827,6 +827,44 @@ def test_fast_policy_rollout_split_bf16(qa):
     assert abs(float(R[:, 0].sum()) - float(g["reward"].sum())) < 1e-2
 
 
+def test_step_policy_one_launch_per_step(qa):
+    """VecDockingEnv.step_policy -- the actor on the matrix cores + the env step in ONE launch per step -- against the loop it
+    stands for, env.step(policy.predict(obs)) (run_trained_docking_ppo2.py:37-60), on the same envs: identical decisions, the
+    same trajectories up to the GEMM rounding; and the reference's closed-loop episode (fixture g5) driven step by step"""
+    import os
+    from conftest import GOLDEN
+    g = load_golden("g5_policy_episode")
+    pol = qa.MlpPolicy.from_npz(os.path.join(GOLDEN, "policy_best_model_v0.npz"))
+    kw = dict(num_envs=1000, randomise=1, seed=5, init_range=qa.C3_INIT_RANGE)
+    e1 = qa.VecDockingEnv("docking-v0", **kw); e2 = qa.VecDockingEnv("docking-v0", **kw)
+    o1 = e1.reset(); e2.reset()
+    for t in range(24):
+        a1 = pol.predict(o1)
+        o1, r1, d1, _ = e1.step(a1)
+        o2, r2, d2, a2 = e2.step_policy(pol)
+        if t == 0:
+            np.testing.assert_allclose(a2.cpu().numpy(), a1.cpu().numpy(), atol=2e-6)     # same obs -> same MLP output
+        same = (d1 == d2).cpu().numpy()
+        assert same.mean() > 0.99
+        np.testing.assert_allclose(o2.cpu().numpy()[same], o1.cpu().numpy()[same], rtol=2e-3, atol=2e-3)
+        np.testing.assert_allclose(r2.cpu().numpy()[same], r1.cpu().numpy()[same], rtol=2e-3, atol=2e-3)
+    assert e1.step_counter == e2.step_counter == 24
+    assert e2.last_flags.shape == (1000,)
+    e1.close(); e2.close()
+    for prec, tol_a, tol_o in (("f32", 5e-3, 2e-3), ("bf16x3", 1e-2, 5e-3)):
+        env = qa.VecDockingEnv("docking-v0", num_envs=70, auto_reset=True)
+        env.reset()
+        A, O, R, F, D = [], [], [], [], []
+        for t in range(600):
+            o, r, d, a = env.step_policy(pol, precision=prec)
+            A.append(a[0].cpu().numpy()); O.append(o[0].cpu().numpy()); R.append(float(r[0])); F.append(int(env.last_flags[0])); D.append(bool(d[0]))
+        env.close()
+        np.testing.assert_allclose(np.array(A), g["actions"], atol=tol_a)
+        np.testing.assert_allclose(np.array(O)[:599], g["obs"][:599], atol=tol_o)
+        assert abs(sum(R) - float(g["reward"].sum())) < 1e-2
+        assert abs(sum(f & 1 for f in F) - 183) <= 4 and D[599] and not any(D[:599])
+
+
 def test_integration_md_stub_runs(qa, monkeypatch):
     """the reference-side ctypes binding printed in INTEGRATION.md section 2 is executable as written (with a stub gym
     namespace, gym being absent here) and reproduces the first steps of the reference trajectory"""
