@@ -1025,6 +1025,25 @@ def extras(args, out, env, pool, make_env, time_steps, verify_private_queue, bar
                             "backend": dist.get_backend(),
                             "what": "qs_rollout_slab(T=%d) + ONE RCCL all_gather of the packed (obs, reward, done) slab "
                                     "(%.1f MB per rank per roll-out)" % (T, T * n * 56 / 1e6)}
+        # the same with roll-out k+1 overlapped with the gather of roll-out k (double-buffered slabs)
+        from quadsim_amd.distributed import SlabGatherPipeline
+        del gathered
+        pipe = SlabGatherPipeline(lambda buf: env.rollout_slab(acts, out=buf), slab.shape, dtype=slab.dtype, device=slab.device, depth=2)
+        for _ in range(3):
+            pipe.step()
+        pipe.flush()
+        torch.cuda.synchronize()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            pipe.step()
+        pipe.flush()
+        torch.cuda.synchronize()
+        w5 = max_over_ranks(time.perf_counter() - t0)
+        out["allgather"]["overlapped"] = {"value": total_envs * T * reps / w5, "unit": "env-steps/s",
+                                          "what": "SlabGatherPipeline(depth=2): the all-gather of roll-out k runs on RCCL's stream "
+                                                  "while roll-out k+1 is computed"}
+        del pipe
 
 
 def _pick(args, env, mk, pool, time_steps, verify_private_queue, max_over_ranks, groups):

@@ -52,6 +52,53 @@ def gather_slab(slab, out=None, group=None):
     return out
 
 
+class SlabGatherPipeline:
+    """Roll-out k+1 overlapped with the all-gather of roll-out k ("overlap (double-buffer) or gather
+    per rollout"): `depth` slab buffers rotate; `produce(slab)` fills one on the caller's stream (qs_rollout_slab), its
+    all-gather is issued asynchronously (RCCL runs it on its own stream, ordered behind the producer) and the next roll-out
+    starts at once.  `step()` returns the gathered [G,T,n,14] tensor of the roll-out submitted `depth` calls earlier (None
+    while the pipeline fills); it stays valid -- for work enqueued on the caller's stream -- until the NEXT call of step()
+    (depth + 1 output buffers rotate); `flush()` returns the ones still in flight, oldest first."""
+
+    def __init__(self, produce, slab_shape, dtype=None, device=None, depth=2, group=None):
+        import torch
+        import torch.distributed as dist
+        self._dist, self.produce, self.group, self.depth = dist, produce, group, max(1, int(depth))
+        self.world = dist.get_world_size(group)
+        dtype = dtype or torch.float32
+        self.slabs = [torch.empty(tuple(slab_shape), dtype=dtype, device=device) for _ in range(self.depth)]
+        self.outs = [torch.empty((self.world,) + tuple(slab_shape), dtype=dtype, device=device) for _ in range(self.depth + 1)]
+        self.works = [None] * self.depth       # per slab: (work, index of its output buffer)
+        self.k = 0
+
+    def _wait(self, i):
+        w, self.works[i] = self.works[i], None
+        if w is None:
+            return None
+        w[0].wait()                            # the caller's stream (or the host, for CPU backends) is behind the gather
+        return self.outs[w[1]]
+
+    def step(self):
+        i, o = self.k % self.depth, self.k % (self.depth + 1)
+        ready = self._wait(i)                  # the gather that last read slab i
+        s = self.slabs[i]
+        self.produce(s)
+        # output buffer o was handed out depth + 1 calls ago: its readers were enqueued before this call
+        w = self._dist.all_gather_into_tensor(self.outs[o].view((self.world * s.shape[0],) + tuple(s.shape[1:])), s,
+                                              group=self.group, async_op=True)
+        self.works[i] = (w, o)
+        self.k += 1
+        return ready
+
+    def flush(self):
+        done = []
+        for j in range(self.depth):
+            r = self._wait((self.k + j) % self.depth)
+            if r is not None:
+                done.append(r)
+        return done
+
+
 def split_slab(slab):
     """[..., 14] -> (obs [..., 12], reward [...], done [...] bool) views"""
     return slab[..., :12], slab[..., 12], slab[..., 13] > 0.5

@@ -117,7 +117,7 @@ import os, sys
 import numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, %r)
 from oracle.pyoracle import Oracle, PAR_NOMINAL
-from quadsim_amd.distributed import env_shard, gather_rollout, gather_slab, rollout_global_view, split_slab
+from quadsim_amd.distributed import env_shard, gather_rollout, gather_slab, rollout_global_view, split_slab, SlabGatherPipeline
 
 dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
 rank, world = dist.get_rank(), dist.get_world_size()
@@ -148,6 +148,23 @@ S = gather_slab(slab)
 if rank == 0:
     so, sr, sd = split_slab(rollout_global_view(S))
     assert np.array_equal(so.numpy(), o1) and np.array_equal(sr.numpy(), r1) and np.array_equal(sd.numpy(), d1.astype(bool))
+# the double-buffered pipeline: roll-out k+1 produced while roll-out k is gathered; results come out in order, one call late
+calls = []
+def produce(buf):
+    calls.append(len(calls)); buf.copy_(slab * float(len(calls)))
+pipe = SlabGatherPipeline(produce, slab.shape, depth=2)
+res = []
+for k in range(5):
+    r = pipe.step()
+    assert (r is None) == (k < 2)
+    if r is not None:
+        assert torch.equal(r, S * float(k - 1))     # valid until the next step() call
+        res.append(r.clone())
+res += [x.clone() for x in pipe.flush()]
+assert len(res) == 5 and calls == list(range(5)) and pipe.flush() == []
+for k, G in enumerate(res):
+    assert torch.equal(G, S * float(k + 1)), k
+if rank == 0:
     print("OK")
 dist.destroy_process_group()
 ''' % ROOT)
