@@ -12,7 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB_PATH = os.environ.get("QUADSIM_HIP_LIB") or os.path.join(CSRC, "libquadsim_hip.so")  # override: A/B builds
 SOURCES = [os.path.join(CSRC, "quadsim_hip.hip")]
-HEADERS = [os.path.join(CSRC, "quadsim_device.hpp"), os.path.join(CSRC, "rollout_ops.hpp"), os.path.join(CSRC, "policy_rollout.hpp"), os.path.join(HERE, "..", "include", "quadsim.h")]
+HEADERS = [os.path.join(CSRC, h) for h in ("quadsim_device.hpp", "step_kernels.hpp", "rollout_ops.hpp", "policy_rollout.hpp", "env_groups.hpp",
+                                          "private_queue.hpp")] + [os.path.join(HERE, "..", "include", "quadsim.h")]
 
 QS_OK = 0
 KIND_V0, KIND_V2, KIND_V1, KIND_HOVER = 0, 1, 2, 3
