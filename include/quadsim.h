@@ -307,7 +307,8 @@ int qs_episode_stats(QsEnv *env, int64_t T, int64_t n, const float *rewards, con
 /* Policy-in-the-loop roll-out in one launch: for t < T:  a_t = clip(MLP(obs_t), -1, 1);  obs_{t+1}, r_t, done_t =
  * env.step(a_t) -- the loop of run_trained_docking_ppo2.py:37-60 for N envs, with the deterministic actor of the
  * shipped PPO2 MlpPolicy (shared_fc0 12->128, pi_fc0 128->128, pi 128->4, ReLU).  Weights are passed TRANSPOSED
- * (out, in), row-major float32 device arrays: wt1 [128,12], b1 [128], wt2 [128,128], b2 [128], wt3 [4,128], b3 [4].
+ * (out, in), row-major float32 device arrays: wt1 [128,12], b1 [128], wt2 [128,128], b2 [128], wt3 [4,128], b3 [4]
+ * (wt2 and wt3 16-byte aligned: they are read as float4).
  * obs [T,N,12] = obs_{t+1}; reward, done, flags [T,N]; actions [T,N,4] nullable = a_t.  The MLP runs on the matrix
  * cores in exact float32 (v_mfma_f32_16x16x4_f32).  docking-v0/v2, auto_reset, randomise 0/1. */
 int qs_policy_rollout(QsEnv *env, int64_t T, const float *wt1, const float *b1, const float *wt2, const float *b2,

@@ -1182,6 +1182,7 @@ int qs_policy_rollout(QsEnv *e, int64_t T, const float *wt1, const float *b1, co
     CHECK_ENV(e);
     if (T < 1 || !wt1 || !b1 || !wt2 || !b2 || !wt3 || !b3 || !obs || !reward || !done)
         return fail(QS_ERR_INVALID, "qs_policy_rollout: bad arguments");
+    if ((((uintptr_t)wt2) | ((uintptr_t)wt3)) & 15u) return fail(QS_ERR_INVALID, "qs_policy_rollout: wt2 and wt3 must be 16-byte aligned");
     if (e->cfg.io_space != QS_IO_DEVICE) return fail(QS_ERR_INVALID, "qs_policy_rollout: device buffers only");
     if (!e->cfg.auto_reset) return fail(QS_ERR_INVALID, "qs_policy_rollout: requires auto_reset");
     if (e->cfg.kind == QS_KIND_HOVERING_V0 || e->per_env_params || e->init || e->cfg.randomise > 1)

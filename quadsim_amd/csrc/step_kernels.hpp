@@ -612,12 +612,43 @@ __global__ __launch_bounds__(kBlock, 1) void k_policy_rollout(StepArgs A, MlpArg
     float *sB3 = sB2 + kHid;
     float *sObsAll = sB3 + 16;
     float *sActAll = sObsAll + 4 * (12 * 64);
-    // weights -> LDS (W3^T rows 4..15 and b3[4..15] are zero padding of the 16-row MFMA tile)
-    for (int i = threadIdx.x; i < kHid * kHid; i += kBlock) sW2[(i >> 7) * kLdW + (i & 127)] = M.wt2[i];
-    for (int i = threadIdx.x; i < 16 * kHid; i += kBlock) sW3[(i >> 7) * kLdW + (i & 127)] = (i >> 7) < 4 ? M.wt3[i] : 0.0f;
-    for (int i = threadIdx.x; i < kHid * 12; i += kBlock) sW1[(i / 12) * kLdW1 + (i % 12)] = M.wt1[i];
-    for (int i = threadIdx.x; i < kHid; i += kBlock) { sB1[i] = M.b1[i]; sB2[i] = M.b2[i]; }
-    if (threadIdx.x < 16) sB3[threadIdx.x] = threadIdx.x < 4 ? M.b3[threadIdx.x] : 0.0f;
+    // weights -> LDS (W3^T rows 4..15 and b3[4..15] are zero padding of the 16-row MFMA tile).  Every request of a thread goes
+    // out before the first LDS write waits for one: a copy loop of load / wait / write pairs costs a launch with T = 1 (one
+    // step per launch, VecDockingEnv.step_policy) one L2 round trip per iteration
+    {
+        static_assert(kHid == 128 && kBlock == 256 && kLdW % 4 == 0, "staging layout");
+        const float4 *w2v = reinterpret_cast<const float4 *>(M.wt2);
+        float4 v2[16], v3[2];
+        float v1[6];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) v2[j] = w2v[j * kBlock + threadIdx.x];                       // 4 096 float4: row i4 >> 5
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i4 = j * kBlock + threadIdx.x;                                              // 512 float4 of the padded tile
+            v3[j] = (i4 >> 5) < 4 ? reinterpret_cast<const float4 *>(M.wt3)[i4] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) v1[j] = M.wt1[j * kBlock + threadIdx.x];                      // 1 536 floats
+        const float vb1 = threadIdx.x < kHid ? M.b1[threadIdx.x] : 0.0f, vb2 = threadIdx.x < kHid ? M.b2[threadIdx.x] : 0.0f;
+        const float vb3 = threadIdx.x < 4 ? M.b3[threadIdx.x] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int i4 = j * kBlock + threadIdx.x;
+            *reinterpret_cast<float4 *>(sW2 + (i4 >> 5) * kLdW + (i4 & 31) * 4) = v2[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i4 = j * kBlock + threadIdx.x;
+            *reinterpret_cast<float4 *>(sW3 + (i4 >> 5) * kLdW + (i4 & 31) * 4) = v3[j];
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const int i = j * kBlock + threadIdx.x;
+            sW1[(i / 12) * kLdW1 + (i % 12)] = v1[j];
+        }
+        if (threadIdx.x < kHid) { sB1[threadIdx.x] = vb1; sB2[threadIdx.x] = vb2; }
+        if (threadIdx.x < 16) sB3[threadIdx.x] = vb3;
+    }
     __syncthreads();
 
     const int lane = threadIdx.x & (kTile - 1);
@@ -659,7 +690,21 @@ template <int INTEG, int RMODE>
 __global__ __launch_bounds__(kBlock, 1) void k_policy_rollout_fast(StepArgs A, const uint4 *__restrict__ blob, float *__restrict__ actions_out)
 {
     __shared__ __attribute__((aligned(16))) char lds[kFastBlobBytes + 4 * (12 * 64 + 64 * 4) * 4];
-    for (int i = threadIdx.x; i < kFastBlobBytes / 16; i += kBlock) reinterpret_cast<uint4 *>(lds)[i] = blob[i];
+    {
+        // all requests first, then the LDS writes (see k_policy_rollout)
+        constexpr int kN16 = kFastBlobBytes / 16, kPer = (kN16 + kBlock - 1) / kBlock;
+        uint4 v[kPer];
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const int i = j * kBlock + threadIdx.x;
+            v[j] = i < kN16 ? blob[i] : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < kPer; ++j) {
+            const int i = j * kBlock + threadIdx.x;
+            if (i < kN16) reinterpret_cast<uint4 *>(lds)[i] = v[j];
+        }
+    }
     __syncthreads();
     const int lane = threadIdx.x & (kTile - 1);
     const int w = threadIdx.x >> 6;
