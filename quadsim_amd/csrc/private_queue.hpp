@@ -358,7 +358,9 @@ int chain_open(QsEnv *e, int nq)
         }
         return QS_OK;
     };
-    const int rc = body();
+    int rc;
+    try { rc = body(); }                                 // no C++ exception may cross the C ABI
+    catch (...) { rc = fail(QS_ERR_NOMEM, "qs_set_queue_mode: out of host memory"); }
     if (rc != QS_OK) chain_close(e);
     return rc;
 }

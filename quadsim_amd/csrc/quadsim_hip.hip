@@ -703,6 +703,8 @@ int qs_set_groups(QsEnv *e, int32_t groups, int32_t launcher_threads)
     HIP_TRY(hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming));
     const int64_t base = e->tiles / groups, rem = e->tiles % groups;
     int64_t t0 = 0;
+    try { e->groups.reserve((size_t)groups); }           // no C++ exception may cross the C ABI (push_back below cannot throw now)
+    catch (...) { return fail(QS_ERR_NOMEM, "qs_set_groups: out of host memory"); }
     for (int32_t i = 0; i < groups; ++i) {
         QsGroup *g = new (std::nothrow) QsGroup();
         if (!g) return fail(QS_ERR_NOMEM, "qs_set_groups: out of host memory");
@@ -888,7 +890,10 @@ int qs_rollout_stepwise(QsEnv *e, int64_t T, const float *actions, float *obs, f
     const int64_t n = e->n;
     StepArgs A = make_args(e);
     std::vector<StepArgs> steps;
-    if (e->chain) steps.reserve((size_t)T);
+    if (e->chain) {
+        try { steps.reserve((size_t)T); }                // no C++ exception may cross the C ABI
+        catch (...) { return fail(QS_ERR_NOMEM, "qs_rollout_stepwise: out of host memory for %lld kernel-argument blocks", (long long)T); }
+    }
     for (int64_t t = 0; t < T; ++t) {
         A.actions = actions + t * n * 4;
         A.obs = obs + t * n * e->obs_dim;
