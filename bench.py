@@ -964,6 +964,34 @@ def extras(args, out, env, pool, make_env, time_steps, verify_private_queue, bar
                                    "hbm_frac": bpe * nb / (wb / 200) / 1e9 / HBM_PEAK_GBS}
         env_b.close()
         del pool_b
+    # what the HBM of THIS box delivers ("report both spec and measured"): device copy and triad over arrays far
+    # beyond the 256 MB Infinity Cache, plain torch ops, HIP events; bytes counted as read + written
+    try:
+        nel = 1 << 28                                                 # 1 GiB of float32 per array
+        xa = torch.empty(nel, dtype=torch.float32, device="cuda:%d" % local_rank).normal_()
+        xb = torch.empty_like(xa).normal_()
+        xc = torch.empty_like(xa)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        res = {}
+        for name, fn, nbytes in (("copy", lambda: xc.copy_(xa), 2 * 4 * nel), ("triad", lambda: torch.add(xa, xb, alpha=1.5, out=xc), 3 * 4 * nel)):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            e0.record()
+            for _ in range(10):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            res[name + "_GBs"] = nbytes * 10 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del xa, xb, xc
+        best = max(res.values())
+        out["hbm_measured"] = dict(res, array_bytes=4 * nel, spec_peak_GBs=HBM_PEAK_GBS, measured_over_spec=best / HBM_PEAK_GBS,
+                                   what="torch device copy / triad over 1 GiB float32 arrays (beyond the Infinity Cache), read + written "
+                                        "bytes per HIP-event time: what this box's HBM delivers to a streaming kernel")
+        if "step_api_1M_envs" in out:
+            out["step_api_1M_envs"]["frac_of_measured_hbm"] = out["step_api_1M_envs"]["hbm_frac"] * HBM_PEAK_GBS / best
+    except Exception as ex:                                           # a micro-benchmark must never cost the line
+        out["hbm_measured"] = {"error": str(ex)}
     # policy in the loop, fused: a = clip(MLP(obs)); env.step(a), T steps per launch, the shipped PPO2
     # actor (weights fixture) on the matrix cores.  Needs nominal / rocRAND-initialised resets and no per-env params.
     if args.randomise <= 1 and os.path.exists(wpath):
