@@ -188,7 +188,13 @@ def cpu_baseline(kind, seconds, seed=1234):
     with ThreadPoolExecutor(cores) as ex:
         total = sum(ex.map(worker, range(cores)))
     dt = time.perf_counter() - t0
-    out = {"value": total / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
+    cpu_model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            cpu_model = next((ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")), "unknown")
+    except OSError:
+        pass
+    out = {"value": total / dt, "unit": "env-steps/s", "cores": cores, "cpu_model": cpu_model, "kind": "port",
            "sample": "C oracle (f64 restatement of the reference path), %d threads x 1024 envs, U(-1,1) actions, "
                      "randomised auto-reset, %.1f s wall" % (cores, dt)}
     # the NumPy twin (oracle/np_oracle.py: the same closed form as array code), one process, 4 096 envs per call
