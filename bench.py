@@ -876,6 +876,36 @@ def extras(args, out, env, pool, make_env, time_steps, verify_private_queue, bar
                 pb["private_stream_ordered"]["env_step_alone_us"] = ws / 500 * 1e6
             except qa.QuadsimError as ex:
                 pb["private_stream_ordered"] = {"invalid": "the placement guard fired during this leg: %s" % ex}
+        # the same per-step loop captured ONCE into a hipGraph (torch.cuda.graphs: 10 x [three GEMMs + activations + qs_step], no
+        # Python, no launch calls at replay; the step counter that keys the reset RNG lives in device memory, so every replay draws
+        # fresh resets) and replayed 30 times
+        try:
+            env.set_queue_mode(False)
+            env.reset()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    pol.predict(env._obs)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr):
+                for _ in range(10):
+                    env.step(pol.predict(env._obs))
+            for _ in range(3):
+                gr.replay()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(30):
+                gr.replay()
+            torch.cuda.synchronize()
+            wp = max_over_ranks(time.perf_counter() - t0) / 300
+            pb["hip_stream_graph"] = {"us_per_step": wp * 1e6, "value": total_envs / wp, "unit": "env-steps/s",
+                                      "what": "10 steps of obs -> MlpPolicy (torch GEMMs) -> qs_step captured into one hipGraph, replayed 30 x"}
+            del gr
+        except Exception as ex:                                       # capture support varies with the torch build: never cost the line
+            pb["hip_stream_graph"] = {"error": str(ex)[:200]}
         # the same loop with the shipped actor INSIDE the launch: VecDockingEnv.step_policy = qs_policy_rollout(T = 1), one launch
         # per step on the HIP stream, outputs consumable per step
         env.set_queue_mode(False)
