@@ -906,6 +906,20 @@ def extras(args, out, env, pool, make_env, time_steps, verify_private_queue, bar
             del gr
         except Exception as ex:                                       # capture support varies with the torch build: never cost the line
             pb["hip_stream_graph"] = {"error": str(ex)[:200]}
+        # the same loop with the actor as ONE hand-written kernel (qs_policy_forward, MlpPolicy.predict_hip) and qs_step as a call of
+        # its own: two launches per step, the full VecEnv return (infos, terminal observations)
+        env.set_queue_mode(False)
+        for prec in ("f32", "bf16x3"):
+            obs = env.reset()
+            for _ in range(30):
+                obs, _, _, _ = env.step(pol.predict_hip(env, obs, precision=prec))
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(300):
+                obs, _, _, _ = env.step(pol.predict_hip(env, obs, precision=prec))
+            torch.cuda.synchronize()
+            wp = max_over_ranks(time.perf_counter() - t0) / 300
+            pb["hip_stream_mfma_policy_" + prec] = {"us_per_step": wp * 1e6, "value": total_envs / wp, "unit": "env-steps/s"}
         # the same loop with the shipped actor INSIDE the launch: VecDockingEnv.step_policy = qs_policy_rollout(T = 1), one launch
         # per step on the HIP stream, outputs consumable per step
         env.set_queue_mode(False)

@@ -37,7 +37,7 @@
 extern "C" {
 #endif
 
-#define QS_VERSION 130 /* 0.1.3: + stream-ordered private queues (qs_set_queue_ordering); 0.1.2: + private-queue mode; 0.1.1: qs_step_ex, env groups, qs_gae_flatten, qs_episode_stats, ... */
+#define QS_VERSION 131 /* 0.1.3.1: + qs_policy_forward; 0.1.3: + stream-ordered private queues (qs_set_queue_ordering); 0.1.2: + private-queue mode; 0.1.1: qs_step_ex, env groups, qs_gae_flatten, qs_episode_stats, ... */
 
 enum {
     QS_OK = 0,
@@ -314,6 +314,17 @@ int qs_episode_stats(QsEnv *env, int64_t T, int64_t n, const float *rewards, con
 int qs_policy_rollout(QsEnv *env, int64_t T, const float *wt1, const float *b1, const float *wt2, const float *b2,
                       const float *wt3, const float *b3, float *obs, float *reward, uint8_t *done, uint8_t *flags,
                       float *actions);
+
+/* The actor alone: actions [n,4] = clip(MLP(obs [n,12]), -1, 1) -- `model.predict(obs, deterministic=True)` of
+ * run_trained_docking_ppo2.py:41 for n rows, on the matrix cores, launched on the handle's stream (the handle lends its
+ * device and stream; n need not be its env count).  The same evaluation as inside qs_policy_rollout, hence the same
+ * bits for the same observations: `qs_policy_forward; qs_step` == `qs_policy_rollout(T = 1)` where the latter's
+ * observation is the stored one.  For loops that need the env step as a call of its own (terminal observations,
+ * infos).  Weights as for qs_policy_rollout; obs and actions device arrays, 16-byte aligned.  _fast: split-bf16
+ * operands, packed_weights as for qs_policy_rollout_fast. */
+int qs_policy_forward(QsEnv *env, int64_t n, const float *wt1, const float *b1, const float *wt2, const float *b2,
+                      const float *wt3, const float *b3, const float *obs, float *actions);
+int qs_policy_forward_fast(QsEnv *env, int64_t n, const void *packed_weights, const float *obs, float *actions);
 
 /* The same roll-out with the actor on the bf16 matrix rate (16x the f32 MFMA rate) and split operands: each f32
  * value is carried as bf16 hi + lo and x*w is evaluated as hi*hi + hi*lo + lo*hi with f32 accumulation -- about 1e-5

@@ -28,6 +28,7 @@ EXPORTS = [
     "qs_rollout", "qs_rollout_slab", "qs_rollout_stepwise", "qs_fill_random_actions", "qs_get_state", "qs_set_state", "qs_set_params", "qs_get_params",
     "qs_set_init_state", "qs_get_init_state", "qs_obs_dim", "qs_get_step_counter", "qs_set_step_counter", "qs_set_stream", "qs_sync", "qs_timer_start", "qs_timer_stop",
     "qs_drone_step", "qs_ctrl", "qs_rel_obs", "qs_transform", "qs_gae", "qs_swap_and_flatten", "qs_expert_action", "qs_policy_rollout", "qs_policy_rollout_fast", "qs_policy_rollout_fast_blob_bytes",
+    "qs_policy_forward", "qs_policy_forward_fast",
     "qs_runner_rollout", "qs_runner_rollout_fast", "qs_runner_rollout_fast_blob_bytes",
     "qs_step_ex", "qs_set_groups", "qs_group_count", "qs_group_range", "qs_group_stream", "qs_group_set_stream",
     "qs_step_group", "qs_step_groups", "qs_groups_fork", "qs_groups_join",
@@ -138,6 +139,8 @@ def load():
         "qs_policy_rollout": [vp, i64] + [vp] * 11,
         "qs_policy_rollout_fast": [vp, i64] + [vp] * 6,
         "qs_policy_rollout_fast_blob_bytes": [],
+        "qs_policy_forward": [vp, i64] + [vp] * 8,
+        "qs_policy_forward_fast": [vp, i64, vp, vp, vp],
         "qs_runner_rollout": [vp, i64, C.POINTER(QsActorCritic)] + [vp] * 12,
         "qs_runner_rollout_fast": [vp, i64, vp, C.POINTER(C.c_float), i32] + [vp] * 12,
         "qs_runner_rollout_fast_blob_bytes": [],

@@ -1206,6 +1206,34 @@ int qs_policy_rollout(QsEnv *e, int64_t T, const float *wt1, const float *b1, co
     return QS_OK;
 }
 
+int qs_policy_forward(QsEnv *e, int64_t n, const float *wt1, const float *b1, const float *wt2, const float *b2, const float *wt3,
+                      const float *b3, const float *obs, float *actions)
+{
+    Range rg_("qs_policy_forward");
+    CHECK_ENV(e);
+    if (n < 1 || !wt1 || !b1 || !wt2 || !b2 || !wt3 || !b3 || !obs || !actions) return fail(QS_ERR_INVALID, "qs_policy_forward: bad arguments");
+    if ((((uintptr_t)wt2) | ((uintptr_t)wt3) | ((uintptr_t)obs) | ((uintptr_t)actions)) & 15u)
+        return fail(QS_ERR_INVALID, "qs_policy_forward: wt2, wt3, obs and actions must be 16-byte aligned");
+    if (e->cfg.io_space != QS_IO_DEVICE) return fail(QS_ERR_INVALID, "qs_policy_forward: device buffers only");
+    MlpArgs M{wt1, b1, wt2, b2, wt3, b3};
+    hipLaunchKernelGGL(k_policy_forward, dim3(grid_tiles(n)), dim3(kBlock), 0, e->stream, M, obs, actions, n);
+    HIP_TRY(hipGetLastError());
+    return QS_OK;
+}
+
+int qs_policy_forward_fast(QsEnv *e, int64_t n, const void *packed_weights, const float *obs, float *actions)
+{
+    Range rg_("qs_policy_forward_fast");
+    CHECK_ENV(e);
+    if (n < 1 || !packed_weights || !obs || !actions) return fail(QS_ERR_INVALID, "qs_policy_forward_fast: bad arguments");
+    if ((((uintptr_t)packed_weights) | ((uintptr_t)obs) | ((uintptr_t)actions)) & 15u)
+        return fail(QS_ERR_INVALID, "qs_policy_forward_fast: packed_weights, obs and actions must be 16-byte aligned");
+    if (e->cfg.io_space != QS_IO_DEVICE) return fail(QS_ERR_INVALID, "qs_policy_forward_fast: device buffers only");
+    hipLaunchKernelGGL(k_policy_forward_fast, dim3(grid_tiles(n)), dim3(kBlock), 0, e->stream, (const uint4 *)packed_weights, obs, actions, n);
+    HIP_TRY(hipGetLastError());
+    return QS_OK;
+}
+
 int qs_policy_rollout_fast(QsEnv *e, int64_t T, const void *packed_weights, float *obs, float *reward, uint8_t *done,
                            uint8_t *flags, float *actions)
 {

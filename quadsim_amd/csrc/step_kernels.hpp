@@ -597,6 +597,126 @@ __global__ __launch_bounds__(3 * kTile) void k_env_split(StepArgs A)
     }
 }
 
+// LDS image of the f32 actor (policy_lds_floats()): W2^T | W3^T (16-row tile) | W1^T | b1 | b2 | b3 (16) | per-wave obs / action staging
+struct MlpLds {
+    float *W2, *W3, *W1, *B1, *B2, *B3, *ObsAll, *ActAll;
+};
+__device__ __forceinline__ MlpLds mlp_lds_layout(float *lds)
+{
+    MlpLds L;
+    L.W2 = lds;
+    L.W3 = L.W2 + kHid * kLdW;
+    L.W1 = L.W3 + 16 * kLdW;
+    L.B1 = L.W1 + kHid * kLdW1;
+    L.B2 = L.B1 + kHid;
+    L.B3 = L.B2 + kHid;
+    L.ObsAll = L.B3 + 16;
+    L.ActAll = L.ObsAll + 4 * (12 * 64);
+    return L;
+}
+// weights -> LDS (W3^T rows 4..15 and b3[4..15] are zero padding of the 16-row MFMA tile), by the 256 threads of a workgroup.
+// Every request of a thread goes out before the first LDS write waits for one: a copy loop of load / wait / write pairs costs a
+// launch with T = 1 (one step per launch, VecDockingEnv.step_policy) one L2 round trip per iteration
+__device__ __forceinline__ void mlp_stage_weights(const MlpArgs &M, const MlpLds &L)
+{
+    static_assert(kHid == 128 && kBlock == 256 && kLdW % 4 == 0, "staging layout");
+    const float4 *w2v = reinterpret_cast<const float4 *>(M.wt2);
+    float4 v2[16], v3[2];
+    float v1[6];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v2[j] = w2v[j * kBlock + threadIdx.x];                       // 4 096 float4: row i4 >> 5
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i4 = j * kBlock + threadIdx.x;                                              // 512 float4 of the padded tile
+        v3[j] = (i4 >> 5) < 4 ? reinterpret_cast<const float4 *>(M.wt3)[i4] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) v1[j] = M.wt1[j * kBlock + threadIdx.x];                      // 1 536 floats
+    const float vb1 = threadIdx.x < kHid ? M.b1[threadIdx.x] : 0.0f, vb2 = threadIdx.x < kHid ? M.b2[threadIdx.x] : 0.0f;
+    const float vb3 = threadIdx.x < 4 ? M.b3[threadIdx.x] : 0.0f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int i4 = j * kBlock + threadIdx.x;
+        *reinterpret_cast<float4 *>(L.W2 + (i4 >> 5) * kLdW + (i4 & 31) * 4) = v2[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int i4 = j * kBlock + threadIdx.x;
+        *reinterpret_cast<float4 *>(L.W3 + (i4 >> 5) * kLdW + (i4 & 31) * 4) = v3[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int i = j * kBlock + threadIdx.x;
+        L.W1[(i / 12) * kLdW1 + (i % 12)] = v1[j];
+    }
+    if (threadIdx.x < kHid) { L.B1[threadIdx.x] = vb1; L.B2[threadIdx.x] = vb2; }
+    if (threadIdx.x < 16) L.B3[threadIdx.x] = vb3;
+}
+// the split-bf16 weight image (host-packed, kFastBlobBytes) verbatim into LDS: all requests first, then the LDS writes
+__device__ __forceinline__ void mlp_stage_blob(const uint4 *__restrict__ blob, char *lds)
+{
+    constexpr int kN16 = kFastBlobBytes / 16, kPer = (kN16 + kBlock - 1) / kBlock;
+    uint4 v[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int i = j * kBlock + threadIdx.x;
+        v[j] = i < kN16 ? blob[i] : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < kPer; ++j) {
+        const int i = j * kBlock + threadIdx.x;
+        if (i < kN16) reinterpret_cast<uint4 *>(lds)[i] = v[j];
+    }
+}
+
+// The actor alone: actions [n,4] = clip(MLP(obs [n,12])) on the matrix cores -- model.predict(obs, deterministic=True) of
+// run_trained_docking_ppo2.py:41 for n rows, for loops that need the env step as a call of its own (terminal observations,
+// infos).  One wave per 64 rows; the same mlp_actor as the fused kernels, hence the same bits for the same observations.
+__global__ __launch_bounds__(kBlock, 1) void k_policy_forward(MlpArgs M, const float *__restrict__ obs, float *__restrict__ actions, int64_t n)
+{
+    __shared__ __attribute__((aligned(16))) float lds[policy_lds_floats()];
+    const MlpLds L = mlp_lds_layout(lds);
+    mlp_stage_weights(M, L);
+    __syncthreads();
+    const int lane = threadIdx.x & (kTile - 1), w = threadIdx.x >> 6;
+    const int64_t row = ((int64_t)blockIdx.x * (kBlock / kTile) + w) * kTile + lane;
+    float o[12], a[4];
+    if (row < n) {
+        const float4 *p = reinterpret_cast<const float4 *>(obs + row * 12);
+        const float4 v0 = p[0], v1 = p[1], v2 = p[2];
+        o[0] = v0.x; o[1] = v0.y; o[2] = v0.z; o[3] = v0.w; o[4] = v1.x; o[5] = v1.y; o[6] = v1.z; o[7] = v1.w;
+        o[8] = v2.x; o[9] = v2.y; o[10] = v2.z; o[11] = v2.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) o[i] = 0.0f;          // MFMA needs the whole wave
+    }
+    mlp_actor(o, a, L.W1, L.B1, L.W2, L.B2, L.W3, L.B3, L.ObsAll + w * (12 * 64), L.ActAll + w * (64 * 4), lane);
+    if (row < n) reinterpret_cast<float4 *>(actions)[row] = make_float4(a[0], a[1], a[2], a[3]);
+}
+
+__global__ __launch_bounds__(kBlock, 1) void k_policy_forward_fast(const uint4 *__restrict__ blob, const float *__restrict__ obs,
+                                                                   float *__restrict__ actions, int64_t n)
+{
+    __shared__ __attribute__((aligned(16))) char lds[kFastBlobBytes + 4 * (12 * 64 + 64 * 4) * 4];
+    mlp_stage_blob(blob, lds);
+    __syncthreads();
+    const int lane = threadIdx.x & (kTile - 1), w = threadIdx.x >> 6;
+    const int64_t row = ((int64_t)blockIdx.x * (kBlock / kTile) + w) * kTile + lane;
+    float *stage = reinterpret_cast<float *>(lds + kFastBlobBytes);
+    float o[12], a[4];
+    if (row < n) {
+        const float4 *p = reinterpret_cast<const float4 *>(obs + row * 12);
+        const float4 v0 = p[0], v1 = p[1], v2 = p[2];
+        o[0] = v0.x; o[1] = v0.y; o[2] = v0.z; o[3] = v0.w; o[4] = v1.x; o[5] = v1.y; o[6] = v1.z; o[7] = v1.w;
+        o[8] = v2.x; o[9] = v2.y; o[10] = v2.z; o[11] = v2.w;
+    } else {
+#pragma unroll
+        for (int i = 0; i < 12; ++i) o[i] = 0.0f;
+    }
+    mlp_actor_fast(o, a, lds, stage + w * (12 * 64), stage + 4 * (12 * 64) + w * (64 * 4), lane);
+    if (row < n) reinterpret_cast<float4 *>(actions)[row] = make_float4(a[0], a[1], a[2], a[3]);
+}
+
 // Policy-in-the-loop roll-out: T steps of  a = clip(MLP(obs));  obs, r, done = env.step(a)  in one launch
 // (run_trained_docking_ppo2.py:37-60 for N envs).  MLP on exact-f32 MFMA (policy_rollout.hpp), env step = the
 // device code of k_env.  obs_0 is derived from the stored state (an observation is always state2rel of the state).
@@ -604,51 +724,10 @@ template <int INTEG, int RMODE>
 __global__ __launch_bounds__(kBlock, 1) void k_policy_rollout(StepArgs A, MlpArgs M, float *__restrict__ actions_out)
 {
     __shared__ __attribute__((aligned(16))) float lds[policy_lds_floats()];
-    float *sW2 = lds;
-    float *sW3 = sW2 + kHid * kLdW;
-    float *sW1 = sW3 + 16 * kLdW;
-    float *sB1 = sW1 + kHid * kLdW1;
-    float *sB2 = sB1 + kHid;
-    float *sB3 = sB2 + kHid;
-    float *sObsAll = sB3 + 16;
-    float *sActAll = sObsAll + 4 * (12 * 64);
-    // weights -> LDS (W3^T rows 4..15 and b3[4..15] are zero padding of the 16-row MFMA tile).  Every request of a thread goes
-    // out before the first LDS write waits for one: a copy loop of load / wait / write pairs costs a launch with T = 1 (one
-    // step per launch, VecDockingEnv.step_policy) one L2 round trip per iteration
-    {
-        static_assert(kHid == 128 && kBlock == 256 && kLdW % 4 == 0, "staging layout");
-        const float4 *w2v = reinterpret_cast<const float4 *>(M.wt2);
-        float4 v2[16], v3[2];
-        float v1[6];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) v2[j] = w2v[j * kBlock + threadIdx.x];                       // 4 096 float4: row i4 >> 5
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int i4 = j * kBlock + threadIdx.x;                                              // 512 float4 of the padded tile
-            v3[j] = (i4 >> 5) < 4 ? reinterpret_cast<const float4 *>(M.wt3)[i4] : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        }
-#pragma unroll
-        for (int j = 0; j < 6; ++j) v1[j] = M.wt1[j * kBlock + threadIdx.x];                      // 1 536 floats
-        const float vb1 = threadIdx.x < kHid ? M.b1[threadIdx.x] : 0.0f, vb2 = threadIdx.x < kHid ? M.b2[threadIdx.x] : 0.0f;
-        const float vb3 = threadIdx.x < 4 ? M.b3[threadIdx.x] : 0.0f;
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int i4 = j * kBlock + threadIdx.x;
-            *reinterpret_cast<float4 *>(sW2 + (i4 >> 5) * kLdW + (i4 & 31) * 4) = v2[j];
-        }
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int i4 = j * kBlock + threadIdx.x;
-            *reinterpret_cast<float4 *>(sW3 + (i4 >> 5) * kLdW + (i4 & 31) * 4) = v3[j];
-        }
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const int i = j * kBlock + threadIdx.x;
-            sW1[(i / 12) * kLdW1 + (i % 12)] = v1[j];
-        }
-        if (threadIdx.x < kHid) { sB1[threadIdx.x] = vb1; sB2[threadIdx.x] = vb2; }
-        if (threadIdx.x < 16) sB3[threadIdx.x] = vb3;
-    }
+    const MlpLds L = mlp_lds_layout(lds);
+    float *const sW1 = L.W1, *const sB1 = L.B1, *const sW2 = L.W2, *const sB2 = L.B2, *const sW3 = L.W3, *const sB3 = L.B3;
+    float *const sObsAll = L.ObsAll, *const sActAll = L.ActAll;
+    mlp_stage_weights(M, L);
     __syncthreads();
 
     const int lane = threadIdx.x & (kTile - 1);
@@ -690,21 +769,7 @@ template <int INTEG, int RMODE>
 __global__ __launch_bounds__(kBlock, 1) void k_policy_rollout_fast(StepArgs A, const uint4 *__restrict__ blob, float *__restrict__ actions_out)
 {
     __shared__ __attribute__((aligned(16))) char lds[kFastBlobBytes + 4 * (12 * 64 + 64 * 4) * 4];
-    {
-        // all requests first, then the LDS writes (see k_policy_rollout)
-        constexpr int kN16 = kFastBlobBytes / 16, kPer = (kN16 + kBlock - 1) / kBlock;
-        uint4 v[kPer];
-#pragma unroll
-        for (int j = 0; j < kPer; ++j) {
-            const int i = j * kBlock + threadIdx.x;
-            v[j] = i < kN16 ? blob[i] : make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < kPer; ++j) {
-            const int i = j * kBlock + threadIdx.x;
-            if (i < kN16) reinterpret_cast<uint4 *>(lds)[i] = v[j];
-        }
-    }
+    mlp_stage_blob(blob, lds);
     __syncthreads();
     const int lane = threadIdx.x & (kTile - 1);
     const int w = threadIdx.x >> 6;

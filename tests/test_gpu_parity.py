@@ -896,6 +896,44 @@ def test_step_policy_one_launch_per_step(qa):
         assert abs(sum(f & 1 for f in F) - 183) <= 4 and D[599] and not any(D[:599])
 
 
+def test_policy_forward_mfma_kernel(qa):
+    """qs_policy_forward (MlpPolicy.predict_hip): the actor alone on the matrix cores against the three torch GEMMs, ragged row
+    counts, both precisions; and `predict_hip -> env.step` is bit for bit `env.step_policy` (the same mlp_actor, the same
+    observation values), so the per-step loop with a call of its own for the env keeps infos / terminal observations at no
+    numerical difference"""
+    import os, torch
+    from conftest import GOLDEN
+    pol = qa.MlpPolicy.from_npz(os.path.join(GOLDEN, "policy_best_model_v0.npz"))
+    env = qa.VecDockingEnv("docking-v0", num_envs=64)
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for n in (1, 63, 64, 65, 1000, 4097):
+        obs = (torch.rand((n, 12), device="cuda", generator=g) - 0.5) * torch.tensor([6, 6, 6, 2, 2, 2, 3, 3, 3, 2, 2, 2], device="cuda")
+        ref = pol.predict(obs)
+        a32 = pol.predict_hip(env, obs)
+        a16 = pol.predict_hip(env, obs, precision="bf16x3")
+        assert a32.shape == (n, 4) and float((a32 - ref).abs().max()) < 5e-6
+        err = float((a16 - ref).abs().max())
+        assert err < 2e-4, err
+    env.close()
+    kw = dict(num_envs=1000, randomise=1, seed=5, init_range=qa.C3_INIT_RANGE, copy=False)
+    e1 = qa.VecDockingEnv("docking-v0", **kw); e2 = qa.VecDockingEnv("docking-v0", **kw)
+    o1 = e1.reset(); e2.reset()
+    n_done = 0
+    e1.set_state(t=np.where(np.arange(1000) % 3 == 0, 595.0, 0.0).astype(np.float32))
+    e2.set_state(t=np.where(np.arange(1000) % 3 == 0, 595.0, 0.0).astype(np.float32))
+    for t in range(20):
+        a1 = pol.predict_hip(e1, o1)
+        o1, r1, d1, info = e1.step(a1)
+        o2, r2, d2, a2 = e2.step_policy(pol)
+        assert torch.equal(a1, a2) and torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2), t
+        n_done += int(d1.sum())
+        if int(d1.sum()):
+            i = int(torch.nonzero(d1)[0])
+            assert info[i]["terminal_observation"].shape == (12,)      # what step_policy cannot give
+    assert n_done >= 300
+    e1.close(); e2.close()
+
+
 def test_integration_md_stub_runs(qa, monkeypatch):
     """the reference-side ctypes binding printed in INTEGRATION.md section 2 is executable as written (with a stub gym
     namespace, gym being absent here) and reproduces the first steps of the reference trajectory"""

@@ -28,7 +28,7 @@ def test_header_symbols_are_exported_by_the_library():
     for name in declared:
         assert hasattr(lib, name), "libquadsim_hip.so does not export %s" % name
     assert sorted(_lib.EXPORTS) == declared
-    assert lib.qs_version() == 130
+    assert lib.qs_version() == 131
 
 
 def test_config_struct_matches_header():
