@@ -173,6 +173,14 @@ def test_step_outputs_are_not_aliased_by_default(qa, torch):
     assert o1.data_ptr() == o2.data_ptr()                             # the documented fast path re-uses its buffers
     assert i1[1]["chaser"].shape == (13,)                             # info_state=True snapshots every step
     env.close()
+    env = qa.VecDockingEnv("docking-v0", num_envs=n, randomise=1, seed=2, init_range=qa.C3_INIT_RANGE, copy=False)
+    env.reset()
+    _, _, _, i1 = env.step(acts[0])
+    assert i1[1]["chaser"].shape == (13,)                             # read before the next step: fine
+    _, _, _, i1 = env.step(acts[1]); env.step(acts[2])
+    with pytest.raises(qa.QuadsimError):
+        i1[0]                                                         # copy=False without snapshots: infos live until the next step
+    env.close()
 
 
 def test_numpy_backend_reports_terminal_states(qa):

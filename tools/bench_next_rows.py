@@ -25,7 +25,7 @@ def timed(fn, reps, warm=5):
 out = {}
 for env_id, bpe in (("docking-v0", 392), ("docking-v2", 392), ("docking-v1", 392 + 0), ("hovering-v0", 17 * 4 + 16 + 17 * 4 + 52 + 4 + 2)):
     env = qa.VecDockingEnv(env_id, num_envs=N, randomise=1 if env_id in ("docking-v0", "docking-v2") else 0, seed=1,
-                           init_range=qa.C3_INIT_RANGE)
+                           init_range=qa.C3_INIT_RANGE, copy=False)     # the fast path of the Python API: outputs valid until the next step
     env.reset()
     acts = env.random_actions(64)
     if env_id == "hovering-v0":
