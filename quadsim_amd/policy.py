@@ -39,8 +39,13 @@ class MlpPolicy:
         import ctypes as C
         import torch
         from . import _lib
+        if (not isinstance(obs, torch.Tensor) or obs.dtype != torch.float32 or obs.dim() != 2 or obs.shape[1] != 12
+                or obs.device != env.device):
+            raise ValueError("predict_hip: obs must be a float32 [n, 12] tensor on %s" % (env.device,))
         obs = obs.contiguous()
         n = int(obs.shape[0])
+        if out is not None and (out.dtype != torch.float32 or tuple(out.shape) != (n, 4) or not out.is_contiguous() or out.device != obs.device):
+            raise ValueError("predict_hip: out must be a contiguous float32 [n, 4] tensor on the same device")
         acts = out if out is not None else torch.empty((n, 4), dtype=torch.float32, device=obs.device)
         p = lambda t: C.c_void_p(t.data_ptr())      # noqa: E731
         env._use_current_stream()
