@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """The loop of the reference's run_trained_docking_ppo2.py:36-60 on the MI355X: the shipped PPO2 actor drives
-docking-v0 for one episode in N parallel envs.  Four ways to run the same loop:
+docking-v0 for one episode in N parallel envs.  Five ways to run the same loop:
 
     python examples/run_trained_docking.py --envs 65536 --mode step      # policy(obs) -> env.step(a), one launch each
+    python examples/run_trained_docking.py --envs 65536 --mode stephip   # policy.predict_hip(env, obs) -> env.step(a): the actor as one MFMA kernel
     python examples/run_trained_docking.py --envs 65536 --mode step1     # env.step_policy(policy): actor + step in ONE launch per step
     python examples/run_trained_docking.py --envs 65536 --mode fused     # whole loop in ONE launch, exact-f32 MFMA
     python examples/run_trained_docking.py --envs 65536 --mode fast      # split-bf16 MFMA actor (~1e-5 action error)
@@ -19,7 +20,7 @@ import quadsim_amd as qa  # noqa: E402
 p = argparse.ArgumentParser()
 p.add_argument("--envs", type=int, default=4096)
 p.add_argument("--steps", type=int, default=600)
-p.add_argument("--mode", default="fused", choices=["step", "step1", "fused", "fast"])
+p.add_argument("--mode", default="fused", choices=["step", "stephip", "step1", "fused", "fast"])
 p.add_argument("--jitter", action="store_true", help="rocRAND-randomised initial states (BASELINE config 3 ranges)")
 args = p.parse_args()
 
@@ -34,6 +35,13 @@ torch.cuda.synchronize()
 t0 = time.perf_counter()
 if args.mode == "step":
     O, R, D, F, A = qa.rollout_with_policy(env, policy, args.steps, obs0=obs)
+elif args.mode == "stephip":                          # the VecEnv protocol as in "step" (infos, terminal observations), actor on the matrix cores
+    rows = []
+    for _ in range(args.steps):
+        a = policy.predict_hip(env, obs)
+        obs, r, d, info = env.step(a)
+        rows.append((obs, r, d, env.last_flags, a))
+    O, R, D, F, A = (torch.stack(x) for x in zip(*rows))
 elif args.mode == "step1":                            # outputs consumable after every step, one launch per step
     rows = []
     for _ in range(args.steps):
