@@ -879,7 +879,8 @@ def extras(args, out, env, pool, make_env, time_steps, verify_private_queue, bar
         # the same per-step loop captured ONCE into a hipGraph (torch.cuda.graphs: 10 x [three GEMMs + activations + qs_step], no
         # Python, no launch calls at replay; the step counter that keys the reset RNG lives in device memory, so every replay draws
         # fresh resets) and replayed 30 times
-        try:
+        gr, gr_err = None, ""
+        try:                                                          # capture support varies with the torch build: never cost the line
             env.set_queue_mode(False)
             env.reset()
             side = torch.cuda.Stream()
@@ -895,6 +896,10 @@ def extras(args, out, env, pool, make_env, time_steps, verify_private_queue, bar
                     env.step(pol.predict(env._obs))
             for _ in range(3):
                 gr.replay()
+            torch.cuda.synchronize()
+        except Exception as ex:
+            gr, gr_err = None, str(ex)[:200]
+        if -max_over_ranks(-float(gr is not None)) > 0.5:             # every rank captured (the timing below holds collectives)
             barrier()
             t0 = time.perf_counter()
             for _ in range(30):
@@ -903,9 +908,9 @@ def extras(args, out, env, pool, make_env, time_steps, verify_private_queue, bar
             wp = max_over_ranks(time.perf_counter() - t0) / 300
             pb["hip_stream_graph"] = {"us_per_step": wp * 1e6, "value": total_envs / wp, "unit": "env-steps/s",
                                       "what": "10 steps of obs -> MlpPolicy (torch GEMMs) -> qs_step captured into one hipGraph, replayed 30 x"}
-            del gr
-        except Exception as ex:                                       # capture support varies with the torch build: never cost the line
-            pb["hip_stream_graph"] = {"error": str(ex)[:200]}
+        else:
+            pb["hip_stream_graph"] = {"error": gr_err or "capture failed on another rank"}
+        del gr
         # the same loop with the actor as ONE hand-written kernel (qs_policy_forward, MlpPolicy.predict_hip) and qs_step as a call of
         # its own: two launches per step, the full VecEnv return (infos, terminal observations)
         env.set_queue_mode(False)
