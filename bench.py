@@ -858,24 +858,40 @@ def extras(args, out, env, pool, make_env, time_steps, verify_private_queue, bar
                 env.set_queue_mode(True, queues, ordering="stream")
                 if env.queue_ordering != "stream":
                     continue
-            obs = env.reset()
-            for _ in range(30):
-                obs, _, _, _ = env.step(pol.predict(obs))
+            # the placement guard may fire on ANY rank in the private mode (it did when two rehearsal ranks shared one GPU): every
+            # rank runs the same sequence of collectives whatever happens, and the leg is marked invalid for all of them
+            err = None
+            try:
+                obs = env.reset()
+                for _ in range(30):
+                    obs, _, _, _ = env.step(pol.predict(obs))
+            except qa.QuadsimError as ex:
+                err = str(ex)
             barrier()
             t0 = time.perf_counter()
-            for _ in range(300):
-                obs, _, _, _ = env.step(pol.predict(obs))
-            torch.cuda.synchronize()
+            if err is None:
+                try:
+                    for _ in range(300):
+                        obs, _, _, _ = env.step(pol.predict(obs))
+                    torch.cuda.synchronize()
+                except qa.QuadsimError as ex:
+                    err = str(ex)
             wp = max_over_ranks(time.perf_counter() - t0) / 300
-            pb[mode] = {"us_per_step": wp * 1e6, "value": total_envs / wp, "unit": "env-steps/s"}
+            if max_over_ranks(float(err is not None)) > 0.5:
+                pb[mode] = {"invalid": "the placement guard fired during this leg%s" % (": " + err[:160] if err else " on another rank")}
+                leave_private(env)
+            else:
+                pb[mode] = {"us_per_step": wp * 1e6, "value": total_envs / wp, "unit": "env-steps/s"}
         # the env side alone, per-step consumable, from the raw C-ABI loop: HIP stream = `hip_stream_mode`; private queue with the
         # per-step hand-shake (hipStreamWriteValue64 + hipStreamWaitValue64 per step are host-bound)
-        if "private_stream_ordered" in pb:
+        if "us_per_step" in pb.get("private_stream_ordered", {}):
+            env.set_queue_mode(True, queues, ordering="stream")
             try:
                 ws, _ = time_steps(env, 500, 1, 50, pool[:16])
                 pb["private_stream_ordered"]["env_step_alone_us"] = ws / 500 * 1e6
             except qa.QuadsimError as ex:
                 pb["private_stream_ordered"] = {"invalid": "the placement guard fired during this leg: %s" % ex}
+        leave_private(env)
         # the same per-step loop captured ONCE into a hipGraph (torch.cuda.graphs: 10 x [three GEMMs + activations + qs_step], no
         # Python, no launch calls at replay; the step counter that keys the reset RNG lives in device memory, so every replay draws
         # fresh resets) and replayed 30 times
