@@ -824,20 +824,30 @@ def extras(args, out, env, pool, make_env, time_steps, verify_private_queue, bar
             env.set_queue_mode(True, queues, ordering="stream")
             if env.queue_ordering != "stream":
                 continue
-        bufs = env.rollout(acts_r, stepwise=True)
+        # as everywhere in this function: a placement-guard error on ONE rank must not change the sequence of collectives
+        err, bufs = None, None
+        try:
+            bufs = env.rollout(acts_r, stepwise=True)
+        except qa.QuadsimError as ex:
+            err = str(ex)
         barrier()
         t0 = time.perf_counter()
-        for _ in range(3):
-            env.rollout(acts_r, stepwise=True, out=bufs)
-        torch.cuda.synchronize()
+        if err is None:
+            try:
+                for _ in range(3):
+                    env.rollout(acts_r, stepwise=True, out=bufs)
+                torch.cuda.synchronize()
+            except qa.QuadsimError as ex:
+                err = str(ex)
         wr = max_over_ranks(time.perf_counter() - t0) / (3 * Tr)
         ro[mode] = {"value": total_envs / wr, "unit": "env-steps/s", "step_period_us": wr * 1e6, "frac": frac_of(wr * 1e6),
                     "read_frac": frac_of(wr * 1e6, rbpe)}
         del bufs
         if mode != "hip":
-            err = leave_private(env)
-            if err:
-                ro[mode] = {"invalid": "the placement guard fired during this leg (several processes on one GPU?): " + err}
+            err = err or leave_private(env)
+        if max_over_ranks(float(bool(err))) > 0.5:
+            ro[mode] = {"invalid": "the placement guard fired during this leg (several processes on one GPU?)" + (": " + err[:160] if err else " on another rank")}
+            leave_private(env)
     ro["T"] = Tr
     ro["what"] = ("qs_rollout_stepwise: T single-step launches per call, outputs of all T steps kept ([T,N,12] obs, [T,N] reward / done / "
                   "flags, %.1f GB per call) and consumable in stream order when the call's hand-shake passes" % (Tr * n * 54 / 1e9))
